@@ -1,0 +1,68 @@
+// Argument blocks shared between forward_kernels.hip (device code + launchers) and
+// forward_api.hip (model handle, weight repacking, orchestration).
+#pragma once
+#include "dc_common.h"
+
+namespace dc {
+
+enum GemmEpilogue {
+  EPI_BIAS = 0,       // C = acc + bias                                   (in_proj)
+  EPI_BIAS_RES,       // C = acc + bias + R                               (out_proj, fc2: residual stream)
+  EPI_BIAS_GELU,      // C = gelu(acc + bias)                             (fc1)
+  EPI_BIAS_RELU_Q,    // C = relu(acc + bias) + q[t]                      (head linear1 + quality residual)
+  EPI_BIAS_RES_RELU,  // C = relu(acc + bias + R)                         (head linear2 + residual)
+};
+
+struct GemmArgs {
+  const float* Wt;    // [K][N]  pre-transposed (and LayerNorm-gamma folded) weights
+  const float* X;     // [K][Tp]
+  float* C;           // [N][Tp]
+  const float* bias;  // [N]     (LayerNorm-beta folded)
+  const float* R;     // [N][Tp] residual or nullptr
+  const float* q;     // [Tp]    quality or nullptr
+  const float* mean;  // [Tp]    LayerNorm statistics of X's tokens (LN variants)
+  const float* rstd;  // [Tp]
+  int K, N;
+  int64_t Tp;
+  int gelu_tanh;
+};
+
+struct FilterArgs {
+  const float *pos_z, *pos_t;
+  const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
+  const float *freq0, *freq1, *freq2;
+  const float *deltas, *bias;
+  int fo, emb, D, max_seq_len, n_taps;
+  float shift;
+  float* out;          // [D][out_stride]
+  int64_t out_stride;
+};
+
+struct HyenaArgs {
+  const float* u;      // [3D][Tp] in_proj output (x0 | x1 | v)
+  float* y;            // [D][Tp]
+  const float* kf;     // [D][kf_stride] long filter of this layer (skip folded into tap 0)
+  int64_t kf_stride;
+  const float* sw;     // [3D][3] short filter
+  const float* sb;     // [3D]
+  const int32_t* grp_reads;  // [n_groups][32] read index or -1
+  const int32_t* grp_P;      // [n_groups] max 32-token blocks over the group's reads
+  const int32_t* toff;       // [n_reads] first token column
+  const int32_t* nblk;       // [n_reads] 32-token blocks
+  int64_t Tp;
+  int D;
+  int CH;              // channels per workgroup (1, 2 or 4)
+};
+
+int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
+int launch_filter(hipStream_t st, const FilterArgs& f);
+int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
+int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
+                 const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                 int64_t Tp, float* x, float* qpad);
+int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd);
+int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
+                    const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                    float* logits);
+
+}  // namespace dc

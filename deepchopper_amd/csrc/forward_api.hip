@@ -1,0 +1,615 @@
+// Model handle, weight repacking and forward orchestration behind the C ABI (F1-F3).
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <vector>
+
+#include "dc_common.h"
+#include "forward.h"
+
+using namespace dc;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct LayerDev {
+  float *Wt_in = nullptr, *b_in = nullptr;    // [D][3D], [3D]   (norm1 folded)
+  float *sw = nullptr, *sb = nullptr;         // [3D][3], [3D]
+  float *Wt_out = nullptr, *b_out = nullptr;  // [D][D], [D]
+  float *Wt_fc1 = nullptr, *b_fc1 = nullptr;  // [D][DI], [DI]  (norm2 folded)
+  float *Wt_fc2 = nullptr, *b_fc2 = nullptr;  // [DI][D], [D]
+  // implicit filter parameters (device copies, checkpoint layout)
+  float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
+        *fw2 = nullptr, *fb2 = nullptr, *fw3 = nullptr, *freq0 = nullptr, *freq1 = nullptr, *freq2 = nullptr,
+        *deltas = nullptr, *fbias = nullptr;
+  float* kf = nullptr;  // [D][kf_taps] materialised long filter
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int tag;
+};
+
+}  // namespace
+
+struct dc_model {
+  dc_model_config cfg{};
+  int device = 0;
+  float* emb = nullptr;
+  std::vector<LayerDev> layers;
+  float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
+  int64_t kf_taps = 0;
+  std::vector<void*> owned;  // every weight allocation
+  int64_t weight_bytes = 0;
+
+  // workspace (grown on demand)
+  DevBuf x, u, y, hmid, obuf, mean, rstd, qpad, idx;
+  int64_t Tp_cap = 0;
+
+  // index arrays: host mirror of the last geometry + pinned staging
+  std::vector<int32_t> h_geom;  // key of the cached geometry
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  hipEvent_t staging_done = nullptr;
+  bool staging_pending = false;
+  // device views into idx
+  int32_t *d_blk_read = nullptr, *d_toff = nullptr, *d_ntok = nullptr, *d_nblk = nullptr, *d_grp_reads = nullptr,
+          *d_grp_P = nullptr;
+  int64_t* d_src_base = nullptr;
+  int64_t Tp = 0;
+  int n_groups = 0, max_P = 0, min_P = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEvent> prof_events;
+  std::vector<hipEvent_t> prof_pool;
+  std::map<std::string, std::pair<double, int64_t>> prof_acc;
+  std::vector<std::string> prof_tags;
+};
+
+namespace {
+
+int dev_alloc(dc_model* m, size_t bytes, void** out) {
+  DC_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4));
+  m->owned.push_back(*out);
+  m->weight_bytes += (int64_t)bytes;
+  return DC_OK;
+}
+
+int upload(dc_model* m, const std::vector<float>& h, float** out) {
+  void* p = nullptr;
+  int rc = dev_alloc(m, h.size() * sizeof(float), &p);
+  if (rc) return rc;
+  DC_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = (float*)p;
+  return DC_OK;
+}
+
+int upload_raw(dc_model* m, const float* h, size_t n, float** out) {
+  std::vector<float> v(h, h + n);
+  return upload(m, v, out);
+}
+
+// Wt[k][n] = W[n][k] * gamma[k];  b'[n] = b[n] + sum_k W[n][k] * beta[k]   (gamma/beta may be null)
+void fold_transpose(const float* W, const float* b, const float* gamma, const float* beta, int N, int K,
+                    std::vector<float>& Wt, std::vector<float>& bo) {
+  Wt.resize((size_t)K * N);
+  bo.resize(N);
+  for (int n = 0; n < N; ++n) {
+    double acc = b ? (double)b[n] : 0.0;
+    const float* wr = W + (size_t)n * K;
+    for (int k = 0; k < K; ++k) {
+      const float g = gamma ? gamma[k] : 1.0f;
+      Wt[(size_t)k * N + n] = wr[k] * g;
+      if (beta) acc += (double)wr[k] * (double)beta[k];
+    }
+    bo[n] = (float)acc;
+  }
+}
+
+int ensure(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return DC_OK;
+  if (b.p) DC_HIP_CHECK(hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  DC_HIP_CHECK(hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return DC_OK;
+}
+
+int ensure_workspace(dc_model* m, int64_t Tp) {
+  if (Tp <= m->Tp_cap) return DC_OK;
+  const auto& c = m->cfg;
+  const size_t f = sizeof(float);
+  int rc;
+  if ((rc = ensure(m->x, (size_t)c.d_model * Tp * f))) return rc;
+  if ((rc = ensure(m->u, (size_t)3 * c.d_model * Tp * f))) return rc;
+  if ((rc = ensure(m->y, (size_t)c.d_model * Tp * f))) return rc;
+  const size_t hm = (size_t)std::max(c.d_inner, c.head_hidden);
+  if ((rc = ensure(m->hmid, hm * Tp * f))) return rc;
+  if ((rc = ensure(m->obuf, (size_t)c.head_hidden * Tp * f))) return rc;
+  if ((rc = ensure(m->mean, (size_t)Tp * f))) return rc;
+  if ((rc = ensure(m->rstd, (size_t)Tp * f))) return rc;
+  if ((rc = ensure(m->qpad, (size_t)Tp * f))) return rc;
+  m->Tp_cap = Tp;
+  return DC_OK;
+}
+
+int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
+  if (taps_needed <= m->kf_taps) return DC_OK;
+  int64_t taps = ((taps_needed + 1023) / 1024) * 1024;
+  const auto& c = m->cfg;
+  for (auto& L : m->layers) {
+    if (L.kf) {
+      DC_HIP_CHECK(hipStreamSynchronize(st));
+      DC_HIP_CHECK(hipFree(L.kf));
+      L.kf = nullptr;
+    }
+    DC_HIP_CHECK(hipMalloc((void**)&L.kf, (size_t)c.d_model * taps * sizeof(float)));
+    FilterArgs f{};
+    f.pos_z = L.pos_z;
+    f.pos_t = L.pos_t;
+    f.w0 = L.fw0; f.b0 = L.fb0; f.w1 = L.fw1; f.b1 = L.fb1; f.w2 = L.fw2; f.b2 = L.fb2; f.w3 = L.fw3;
+    f.freq0 = L.freq0; f.freq1 = L.freq1; f.freq2 = L.freq2;
+    f.deltas = L.deltas;
+    f.bias = L.fbias;
+    f.fo = c.filter_order;
+    f.emb = c.emb_dim;
+    f.D = c.d_model;
+    f.max_seq_len = c.max_seq_len;
+    f.n_taps = (int)taps;
+    f.shift = c.filter_shift;
+    f.out = L.kf;
+    f.out_stride = taps;
+    int rc = launch_filter(st, f);
+    if (rc) return rc;
+  }
+  m->kf_taps = taps;
+  return DC_OK;
+}
+
+// ---- profiling helpers -------------------------------------------------------------------
+int prof_tag(dc_model* m, const char* name) {
+  for (size_t i = 0; i < m->prof_tags.size(); ++i)
+    if (m->prof_tags[i] == name) return (int)i;
+  m->prof_tags.push_back(name);
+  return (int)m->prof_tags.size() - 1;
+}
+
+hipEvent_t prof_get_event(dc_model* m) {
+  if (!m->prof_pool.empty()) {
+    hipEvent_t e = m->prof_pool.back();
+    m->prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+struct ProfScope {
+  dc_model* m;
+  hipStream_t st;
+  ProfEvent ev{};
+  bool on;
+  ProfScope(dc_model* m_, hipStream_t st_, const char* name) : m(m_), st(st_), on(m_->profiling) {
+    if (!on) return;
+    ev.a = prof_get_event(m);
+    ev.b = prof_get_event(m);
+    ev.tag = prof_tag(m, name);
+    if (!ev.a || !ev.b) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(ev.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, st);
+    m->prof_events.push_back(ev);
+  }
+};
+
+int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, const float* X, float* C,
+             const float* bias, const float* R, const float* q, bool ln, int epi, int K, int N) {
+  GemmArgs g{};
+  g.Wt = Wt;
+  g.X = X;
+  g.C = C;
+  g.bias = bias;
+  g.R = R;
+  g.q = q;
+  g.mean = (const float*)m->mean.p;
+  g.rstd = (const float*)m->rstd.p;
+  g.K = K;
+  g.N = N;
+  g.Tp = m->Tp;
+  g.gelu_tanh = m->cfg.gelu_tanh;
+  ProfScope ps(m, st, name);
+  return launch_gemm(st, g, epi, ln);
+}
+
+// Build (or reuse) the packed-layout index arrays for a batch geometry.
+int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride, const int32_t* h_first,
+                   const int32_t* h_ntok) {
+  // geometry key
+  std::vector<int32_t> key;
+  key.reserve(2 * (size_t)n_reads + 3);
+  key.push_back(n_reads);
+  key.push_back((int32_t)(row_stride & 0x7fffffff));
+  key.push_back((int32_t)(row_stride >> 31));
+  key.insert(key.end(), h_first, h_first + n_reads);
+  key.insert(key.end(), h_ntok, h_ntok + n_reads);
+  if (key == m->h_geom && m->Tp > 0) return DC_OK;
+
+  std::vector<int32_t> nblk(n_reads), toff(n_reads);
+  int64_t blocks = 0;
+  int maxP = 0, minP = 1 << 30;
+  for (int r = 0; r < n_reads; ++r) {
+    DC_REQUIRE(h_ntok[r] >= 1, "every read needs at least one token");
+    DC_REQUIRE(h_first[r] >= 0 && (int64_t)h_first[r] + h_ntok[r] <= row_stride, "read exceeds its row");
+    nblk[r] = (h_ntok[r] + 31) / 32;
+    DC_REQUIRE(blocks * 32 < (int64_t)1 << 31, "batch too large for 32-bit token offsets");
+    toff[r] = (int32_t)(blocks * 32);
+    blocks += nblk[r];
+    maxP = std::max(maxP, nblk[r]);
+    minP = std::min(minP, nblk[r]);
+  }
+  const int64_t Tp = ((blocks * 32 + 127) / 128) * 128;
+  DC_REQUIRE(Tp < ((int64_t)1 << 31), "batch too large (token count must fit int32)");
+  DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
+  const int64_t n_tb = Tp / 32;
+
+  // groups of 32 reads of similar length (longest first) for the long-convolution kernel
+  std::vector<int32_t> order(n_reads);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
+  const int n_groups = (n_reads + 31) / 32;
+  std::vector<int32_t> grp_reads((size_t)n_groups * 32, -1), grp_P(n_groups, 0);
+  for (int j = 0; j < n_reads; ++j) {
+    grp_reads[j] = order[j];
+    grp_P[j / 32] = std::max(grp_P[j / 32], nblk[order[j]]);
+  }
+  std::vector<int32_t> blk_read(n_tb, -1);
+  std::vector<int64_t> src_base(n_reads);
+  for (int r = 0; r < n_reads; ++r) {
+    for (int b = 0; b < nblk[r]; ++b) blk_read[toff[r] / 32 + b] = r;
+    src_base[r] = (int64_t)r * row_stride + h_first[r];
+  }
+
+  // layout inside one staging / device buffer (all 8-byte aligned)
+  auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+  size_t o_src = 0;
+  size_t o_blk = al8(o_src + sizeof(int64_t) * n_reads);
+  size_t o_toff = al8(o_blk + sizeof(int32_t) * n_tb);
+  size_t o_ntok = al8(o_toff + sizeof(int32_t) * n_reads);
+  size_t o_nblk = al8(o_ntok + sizeof(int32_t) * n_reads);
+  size_t o_gr = al8(o_nblk + sizeof(int32_t) * n_reads);
+  size_t o_gp = al8(o_gr + sizeof(int32_t) * grp_reads.size());
+  size_t total = al8(o_gp + sizeof(int32_t) * n_groups);
+
+  if (m->staging_pending) {
+    DC_HIP_CHECK(hipEventSynchronize(m->staging_done));
+    m->staging_pending = false;
+  }
+  if (m->pinned_bytes < total) {
+    if (m->pinned) DC_HIP_CHECK(hipHostFree(m->pinned));
+    m->pinned = nullptr;
+    DC_HIP_CHECK(hipHostMalloc(&m->pinned, total, hipHostMallocDefault));
+    m->pinned_bytes = total;
+  }
+  if (m->idx.bytes < total) {
+    DC_HIP_CHECK(hipStreamSynchronize(st));  // an earlier forward may still read the old arrays
+    int rc = ensure(m->idx, total);
+    if (rc) return rc;
+  }
+  char* hp = (char*)m->pinned;
+  memcpy(hp + o_src, src_base.data(), sizeof(int64_t) * n_reads);
+  memcpy(hp + o_blk, blk_read.data(), sizeof(int32_t) * n_tb);
+  memcpy(hp + o_toff, toff.data(), sizeof(int32_t) * n_reads);
+  memcpy(hp + o_ntok, h_ntok, sizeof(int32_t) * n_reads);
+  memcpy(hp + o_nblk, nblk.data(), sizeof(int32_t) * n_reads);
+  memcpy(hp + o_gr, grp_reads.data(), sizeof(int32_t) * grp_reads.size());
+  memcpy(hp + o_gp, grp_P.data(), sizeof(int32_t) * n_groups);
+  DC_HIP_CHECK(hipMemcpyAsync(m->idx.p, m->pinned, total, hipMemcpyHostToDevice, st));
+  DC_HIP_CHECK(hipEventRecord(m->staging_done, st));
+  m->staging_pending = true;
+
+  char* dp = (char*)m->idx.p;
+  m->d_src_base = (int64_t*)(dp + o_src);
+  m->d_blk_read = (int32_t*)(dp + o_blk);
+  m->d_toff = (int32_t*)(dp + o_toff);
+  m->d_ntok = (int32_t*)(dp + o_ntok);
+  m->d_nblk = (int32_t*)(dp + o_nblk);
+  m->d_grp_reads = (int32_t*)(dp + o_gr);
+  m->d_grp_P = (int32_t*)(dp + o_gp);
+  m->Tp = Tp;
+  m->n_groups = n_groups;
+  m->max_P = maxP;
+  m->min_P = minP;
+  m->h_geom.swap(key);
+  return DC_OK;
+}
+
+int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, const float* d_quals, int n_reads,
+                 int64_t row_stride, const int32_t* h_first, const int32_t* h_ntok, float* d_logits) {
+  const auto& c = m->cfg;
+  int rc;
+  if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
+  if ((rc = ensure_workspace(m, m->Tp))) return rc;
+  if ((rc = ensure_filters(m, st, (int64_t)m->max_P * 32))) return rc;
+
+  const int D = c.d_model, DI = c.d_inner, H = c.head_hidden;
+  float* x = (float*)m->x.p;
+  float* u = (float*)m->u.p;
+  float* y = (float*)m->y.p;
+  float* hm = (float*)m->hmid.p;
+  float* ob = (float*)m->obuf.p;
+  float* mean = (float*)m->mean.p;
+  float* rstd = (float*)m->rstd.p;
+  float* qpad = (float*)m->qpad.p;
+  const int64_t Tp = m->Tp;
+
+  ProfScope whole(m, st, "forward");
+  {
+    ProfScope ps(m, st, "embed");
+    if ((rc = launch_embed(st, d_ids, ids_i64, d_quals, m->emb, c.vocab, D, m->d_blk_read, m->d_toff, m->d_src_base,
+                           m->d_ntok, Tp, x, qpad)))
+      return rc;
+  }
+  // channels per workgroup of the long-convolution kernel: keep all four waves busy on short reads
+  const int nchunk_min = (m->max_P + 3) / 4;
+  const int CH = nchunk_min >= 7 ? 1 : (nchunk_min >= 3 ? 2 : 4);
+
+  for (int li = 0; li < c.n_layer; ++li) {
+    LayerDev& L = m->layers[li];
+    {
+      ProfScope ps(m, st, "ln_stats");
+      if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+    }
+    if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D, 3 * D)))
+      return rc;
+    {
+      HyenaArgs a{};
+      a.u = u;
+      a.y = y;
+      a.kf = L.kf;
+      a.kf_stride = m->kf_taps;
+      a.sw = L.sw;
+      a.sb = L.sb;
+      a.grp_reads = m->d_grp_reads;
+      a.grp_P = m->d_grp_P;
+      a.toff = m->d_toff;
+      a.nblk = m->d_nblk;
+      a.Tp = Tp;
+      a.D = D;
+      a.CH = CH;
+      ProfScope ps(m, st, "hyena");
+      if ((rc = launch_hyena(st, a, m->n_groups, m->max_P))) return rc;
+    }
+    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, y, x, L.b_out, x, nullptr, false, EPI_BIAS_RES, D, D)))
+      return rc;
+    {
+      ProfScope ps(m, st, "ln_stats");
+      if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+    }
+    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D, DI)))
+      return rc;
+    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, hm, x, L.b_fc2, x, nullptr, false, EPI_BIAS_RES, DI, D)))
+      return rc;
+  }
+  {
+    ProfScope ps(m, st, "ln_stats");
+    if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+  }
+  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H)))
+    return rc;
+  if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU, H, H)))
+    return rc;
+  {
+    ProfScope ps(m, st, "head_out");
+    if ((rc = launch_head_out(st, ob, m->W3, m->b3, H, c.num_class, Tp, m->d_blk_read, m->d_toff, m->d_src_base,
+                              m->d_ntok, d_logits)))
+      return rc;
+  }
+  return DC_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weights* w, dc_model** out) {
+  DC_REQUIRE(cfg && w && out, "null pointer");
+  DC_REQUIRE(cfg->d_model == 256, "this build is specialised for d_model == 256 (dc_hg.py:96,147)");
+  DC_REQUIRE(cfg->d_inner % 128 == 0 && cfg->head_hidden % 128 == 0, "d_inner / head_hidden must be multiples of 128");
+  DC_REQUIRE(cfg->num_class == 2, "num_class must be 2");
+  DC_REQUIRE(cfg->short_filter_order == 3, "short_filter_order must be 3");
+  DC_REQUIRE(cfg->filter_order <= 64 && cfg->emb_dim <= 8, "implicit filter wider than supported");
+  DC_REQUIRE(cfg->n_layer >= 1 && cfg->vocab >= 1 && cfg->vocab <= 256, "bad n_layer / vocab");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    set_error("no HIP device available: libdeepchopper_hip has no CPU fallback");
+    return DC_ERR_NO_DEVICE;
+  }
+  dc_model* m = new dc_model();
+  m->cfg = *cfg;
+  DC_HIP_CHECK(hipGetDevice(&m->device));
+  DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
+  const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;
+  int rc;
+#define UP(expr)        \
+  if ((rc = (expr))) {  \
+    dc_model_free(m);   \
+    return rc;          \
+  }
+  UP(upload_raw(m, w->embedding, (size_t)cfg->vocab * D, &m->emb));
+  m->layers.resize(cfg->n_layer);
+  std::vector<float> Wt, bo;
+  for (int li = 0; li < cfg->n_layer; ++li) {
+    const dc_layer_weights& lw = w->layers[li];
+    LayerDev& L = m->layers[li];
+    fold_transpose(lw.in_proj_w, lw.in_proj_b, lw.norm1_w, lw.norm1_b, 3 * D, D, Wt, bo);
+    UP(upload(m, Wt, &L.Wt_in));
+    UP(upload(m, bo, &L.b_in));
+    UP(upload_raw(m, lw.short_w, (size_t)3 * D * 3, &L.sw));
+    UP(upload_raw(m, lw.short_b, (size_t)3 * D, &L.sb));
+    fold_transpose(lw.out_proj_w, lw.out_proj_b, nullptr, nullptr, D, D, Wt, bo);
+    UP(upload(m, Wt, &L.Wt_out));
+    UP(upload(m, bo, &L.b_out));
+    fold_transpose(lw.fc1_w, lw.fc1_b, lw.norm2_w, lw.norm2_b, DI, D, Wt, bo);
+    UP(upload(m, Wt, &L.Wt_fc1));
+    UP(upload(m, bo, &L.b_fc1));
+    fold_transpose(lw.fc2_w, lw.fc2_b, nullptr, nullptr, D, DI, Wt, bo);
+    UP(upload(m, Wt, &L.Wt_fc2));
+    UP(upload(m, bo, &L.b_fc2));
+    UP(upload_raw(m, lw.pos_z, (size_t)cfg->max_seq_len * emb, &L.pos_z));
+    UP(upload_raw(m, lw.pos_t, (size_t)cfg->max_seq_len, &L.pos_t));
+    UP(upload_raw(m, lw.filt_w0, (size_t)fo * emb, &L.fw0));
+    UP(upload_raw(m, lw.filt_b0, fo, &L.fb0));
+    UP(upload_raw(m, lw.filt_w1, (size_t)fo * fo, &L.fw1));
+    UP(upload_raw(m, lw.filt_b1, fo, &L.fb1));
+    UP(upload_raw(m, lw.filt_w2, (size_t)fo * fo, &L.fw2));
+    UP(upload_raw(m, lw.filt_b2, fo, &L.fb2));
+    UP(upload_raw(m, lw.filt_w3, (size_t)D * fo, &L.fw3));
+    UP(upload_raw(m, lw.filt_freq0, fo, &L.freq0));
+    UP(upload_raw(m, lw.filt_freq1, fo, &L.freq1));
+    UP(upload_raw(m, lw.filt_freq2, fo, &L.freq2));
+    UP(upload_raw(m, lw.deltas, D, &L.deltas));
+    UP(upload_raw(m, lw.filt_bias, D, &L.fbias));
+  }
+  fold_transpose(w->head_w1, w->head_b1, w->ln_f_w, w->ln_f_b, H, D, Wt, bo);
+  UP(upload(m, Wt, &m->Wt_l1));
+  UP(upload(m, bo, &m->b_l1));
+  fold_transpose(w->head_w2, w->head_b2, nullptr, nullptr, H, H, Wt, bo);
+  UP(upload(m, Wt, &m->Wt_l2));
+  UP(upload(m, bo, &m->b_l2));
+  UP(upload_raw(m, w->head_w3, (size_t)cfg->num_class * H, &m->W3));
+  UP(upload_raw(m, w->head_b3, cfg->num_class, &m->b3));
+#undef UP
+  *out = m;
+  return DC_OK;
+}
+
+extern "C" void dc_model_free(dc_model* m) {
+  if (!m) return;
+  (void)hipDeviceSynchronize();
+  for (void* p : m->owned) (void)hipFree(p);
+  for (auto& L : m->layers)
+    if (L.kf) (void)hipFree(L.kf);
+  for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx})
+    if (b->p) (void)hipFree(b->p);
+  if (m->pinned) (void)hipHostFree(m->pinned);
+  if (m->staging_done) (void)hipEventDestroy(m->staging_done);
+  for (auto& e : m->prof_events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto e : m->prof_pool) (void)hipEventDestroy(e);
+  delete m;
+}
+
+extern "C" int dc_forward(dc_model* m, void* stream, const void* d_input_ids, int32_t ids_i64,
+                          const float* d_input_quals, int32_t batch, int32_t seq_len, float* d_logits) {
+  DC_REQUIRE(m && d_input_ids && d_input_quals && d_logits, "null pointer");
+  DC_REQUIRE(batch >= 1 && seq_len >= 1, "batch and seq_len must be positive");
+  std::vector<int32_t> first(batch, 0), ntok(batch, seq_len);
+  return forward_core(m, as_stream(stream), d_input_ids, ids_i64, d_input_quals, batch, seq_len, first.data(),
+                      ntok.data(), d_logits);
+}
+
+extern "C" int dc_forward_ragged(dc_model* m, void* stream, const void* d_input_ids, int32_t ids_i64,
+                                 const float* d_input_quals, int32_t n_reads, int64_t row_stride,
+                                 const int32_t* h_first, const int32_t* h_n_tokens, float* d_logits) {
+  DC_REQUIRE(m && d_input_ids && d_input_quals && d_logits && h_first && h_n_tokens, "null pointer");
+  DC_REQUIRE(n_reads >= 1 && row_stride >= 1, "n_reads and row_stride must be positive");
+  return forward_core(m, as_stream(stream), d_input_ids, ids_i64, d_input_quals, n_reads, row_stride, h_first,
+                      h_n_tokens, d_logits);
+}
+
+extern "C" int64_t dc_model_device_bytes(const dc_model* m) {
+  if (!m) return 0;
+  int64_t b = m->weight_bytes;
+  b += (int64_t)m->layers.size() * m->cfg.d_model * m->kf_taps * (int64_t)sizeof(float);
+  for (const DevBuf* d : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx})
+    b += (int64_t)d->bytes;
+  return b;
+}
+
+extern "C" int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t seq_len, float* d_out) {
+  DC_REQUIRE(m && d_out, "null pointer");
+  DC_REQUIRE(layer >= 0 && layer < m->cfg.n_layer, "layer out of range");
+  DC_REQUIRE(seq_len >= 1, "seq_len must be positive");
+  hipStream_t st = as_stream(stream);
+  int rc = ensure_filters(m, st, seq_len);
+  if (rc) return rc;
+  DC_HIP_CHECK(hipMemcpy2DAsync(d_out, (size_t)seq_len * sizeof(float), m->layers[layer].kf,
+                                (size_t)m->kf_taps * sizeof(float), (size_t)seq_len * sizeof(float), m->cfg.d_model,
+                                hipMemcpyDeviceToDevice, st));
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_profiling(dc_model* m, int32_t enabled) {
+  DC_REQUIRE(m, "null pointer");
+  m->profiling = enabled != 0;
+  return DC_OK;
+}
+
+extern "C" int dc_model_profile_reset(dc_model* m) {
+  DC_REQUIRE(m, "null pointer");
+  for (auto& e : m->prof_events) {
+    m->prof_pool.push_back(e.a);
+    m->prof_pool.push_back(e.b);
+  }
+  m->prof_events.clear();
+  m->prof_acc.clear();
+  return DC_OK;
+}
+
+// Fold finished event pairs into per-stage totals.  The caller must have synchronised the stream.
+static int prof_collect(dc_model* m) {
+  for (auto& e : m->prof_events) {
+    float ms = 0.f;
+    DC_HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+    auto& acc = m->prof_acc[m->prof_tags[e.tag]];
+    acc.first += ms;
+    acc.second += 1;
+    m->prof_pool.push_back(e.a);
+    m->prof_pool.push_back(e.b);
+  }
+  m->prof_events.clear();
+  return DC_OK;
+}
+
+extern "C" int dc_model_profile_get(dc_model* m, const char* stage, double* total_ms, int64_t* launches) {
+  DC_REQUIRE(m && stage && total_ms && launches, "null pointer");
+  int rc = prof_collect(m);
+  if (rc) return rc;
+  auto it = m->prof_acc.find(stage);
+  if (it == m->prof_acc.end()) {
+    *total_ms = 0.0;
+    *launches = 0;
+    return DC_OK;
+  }
+  *total_ms = it->second.first;
+  *launches = it->second.second;
+  return DC_OK;
+}
+
+extern "C" int dc_model_profile_stages(dc_model* m, char* buf, int32_t buf_len) {
+  DC_REQUIRE(m && buf && buf_len > 0, "bad arguments");
+  int rc = prof_collect(m);
+  if (rc) return rc;
+  std::string s;
+  for (auto& kv : m->prof_acc) {
+    if (!s.empty()) s += ",";
+    s += kv.first;
+  }
+  snprintf(buf, (size_t)buf_len, "%s", s.c_str());
+  return DC_OK;
+}

@@ -1,0 +1,520 @@
+// Forward kernels (F1-F3) for gfx950.
+//
+// Data layout: every activation is CHANNEL-MAJOR, X[C][Tp] fp32, where the token axis Tp is the
+// concatenation of all reads of the batch, each read starting at a multiple of 32 tokens
+// ("packed varlen").  With tokens on the fast axis
+//   * a GEMM  C[n][t] = sum_k Wt[k][n] X[k][t]  puts the output channel on the MFMA row (A operand =
+//     pre-transposed weights) and the token on the MFMA column (B operand), so both operands are
+//     k-major, LDS fragment reads are conflict-free ds_read_b32 with unit lane stride, and the
+//     result tile stores 128 contiguous bytes per accumulator register;
+//   * LayerNorm statistics are per MFMA column, i.e. per lane: normalisation is one FMA on the
+//     B fragment (gamma / beta are folded into the weights at load time);
+//   * the Hyena long convolution reads each (read, channel) sequence contiguously.
+//
+// Arithmetic: fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain).
+#include "dc_common.h"
+#include "forward.h"
+
+namespace dc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =====================================================================================
+// GEMM  C[N][Tp] = Wt[K][N]^T * X[K][Tp]  (+ fused prologue / epilogue)
+// =====================================================================================
+constexpr int G_BN = 128;  // output channels per block
+constexpr int G_BT = 128;  // tokens per block
+constexpr int G_BK = 32;
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+template <int EPI, bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  __shared__ float sA[2][G_BK][G_BN];
+  __shared__ float sB[2][G_BK][G_BT];
+
+  // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous
+  // range of logical ids so that the N/128 blocks that share one token panel hit the same L2.
+  const unsigned nwg = gridDim.x;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n_blocks = g.N / G_BN;
+  const int nb = bid % n_blocks;
+  const int64_t tb = bid / n_blocks;
+  const int n_blk = nb * G_BN;
+  const int64_t t_blk = tb * G_BT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wt = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+
+  // staging coordinates: 32 rows x 32 float4 per tile, 4 float4 per thread
+  const int ld_row = tid >> 5;        // 0..7 (+8 j)
+  const int ld_col = (tid & 31) * 4;  // float offset
+  const float* gA = g.Wt + (int64_t)ld_row * g.N + n_blk + ld_col;
+  const float* gB = g.X + (int64_t)ld_row * g.Tp + t_blk + ld_col;
+
+  float4 ra[4], rb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ra[j] = *reinterpret_cast<const float4*>(gA + (int64_t)(8 * j) * g.N);
+    rb[j] = *reinterpret_cast<const float4*>(gB + (int64_t)(8 * j) * g.Tp);
+  }
+
+  float rs[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f};
+  if (LN) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+      const float m = g.mean[t], r = g.rstd[t];
+      rs[ni] = r;
+      nm[ni] = -m * r;
+    }
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<float4*>(&sA[0][ld_row + 8 * j][ld_col]) = ra[j];
+    *reinterpret_cast<float4*>(&sB[0][ld_row + 8 * j][ld_col]) = rb[j];
+  }
+  __syncthreads();
+
+  const int nk = g.K / G_BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const float* pa = gA + (int64_t)(kt + 1) * G_BK * g.N;
+      const float* pb = gB + (int64_t)(kt + 1) * G_BK * g.Tp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = *reinterpret_cast<const float4*>(pa + (int64_t)(8 * j) * g.N);
+        rb[j] = *reinterpret_cast<const float4*>(pb + (int64_t)(8 * j) * g.Tp);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < G_BK / 2; ++s) {
+      const int kk = 2 * s + h;
+      float a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = sA[cur][kk][wn * 64 + mi * 32 + i];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        b[ni] = sB[cur][kk][wt * 64 + ni * 32 + i];
+        if (LN) b[ni] = fmaf(b[ni], rs[ni], nm[ni]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float4*>(&sA[cur ^ 1][ld_row + 8 * j][ld_col]) = ra[j];
+        *reinterpret_cast<float4*>(&sB[cur ^ 1][ld_row + 8 * j][ld_col]) = rb[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C[n][t], n = row of the accumulator, t = lane column
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+      float qv = 0.f;
+      if (EPI == EPI_BIAS_RELU_Q) qv = g.q[t];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n_blk + wn * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int64_t idx = (int64_t)n * g.Tp + t;
+        float v = acc[mi][ni][e] + g.bias[n];
+        if (EPI == EPI_BIAS_RES) v += g.R[idx];
+        if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
+        if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;            // head.py:94,97
+        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + g.R[idx], 0.f);    // head.py:98
+        g.C[idx] = v;
+      }
+    }
+  }
+}
+
+template <int EPI, bool LN>
+static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
+  const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
+  hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln) {
+  DC_REQUIRE(g.N % G_BN == 0 && g.K % G_BK == 0 && g.Tp % G_BT == 0, "gemm shape not tile aligned");
+  if (ln) {
+    switch (epi) {
+      case EPI_BIAS: return launch_gemm_t<EPI_BIAS, true>(st, g);
+      case EPI_BIAS_GELU: return launch_gemm_t<EPI_BIAS_GELU, true>(st, g);
+      case EPI_BIAS_RELU_Q: return launch_gemm_t<EPI_BIAS_RELU_Q, true>(st, g);
+      default: break;
+    }
+  } else {
+    switch (epi) {
+      case EPI_BIAS_RES: return launch_gemm_t<EPI_BIAS_RES, false>(st, g);
+      case EPI_BIAS_RES_RELU: return launch_gemm_t<EPI_BIAS_RES_RELU, false>(st, g);
+      default: break;
+    }
+  }
+  set_error("unsupported gemm variant epi=%d ln=%d", epi, (int)ln);
+  return DC_ERR_UNSUPPORTED;
+}
+
+// =====================================================================================
+// Embedding gather + quality scatter into the packed channel-major layout
+// =====================================================================================
+template <typename IdT>
+__global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids, const float* __restrict__ quals,
+                                                    const float* __restrict__ emb, int vocab, int D,
+                                                    const int32_t* __restrict__ blk_read,
+                                                    const int32_t* __restrict__ toff,
+                                                    const int64_t* __restrict__ src_base,
+                                                    const int32_t* __restrict__ ntok, int64_t Tp,
+                                                    float* __restrict__ x, float* __restrict__ qpad) {
+  extern __shared__ float s_emb[];  // [vocab][D]
+  for (int j = threadIdx.x; j < vocab * D; j += 256) s_emb[j] = emb[j];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tp) return;
+  const int r = blk_read[t >> 5];
+  int id = -1;
+  float qv = 0.f;
+  if (r >= 0) {
+    const int l = (int)(t - toff[r]);
+    if (l < ntok[r]) {
+      const int64_t s = src_base[r] + l;
+      id = (int)ids[s];
+      qv = quals[s];
+      if (id < 0 || id >= vocab) id = -1;  // out-of-vocabulary ids cannot occur from dc_tokenize_batch
+    }
+  }
+  qpad[t] = qv;
+  for (int c = 0; c < D; ++c) x[(int64_t)c * Tp + t] = id >= 0 ? s_emb[id * D + c] : 0.f;
+}
+
+// =====================================================================================
+// LayerNorm statistics per token (mean, 1/sqrt(var + eps)), two-pass in registers
+// =====================================================================================
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int D, int64_t Tp, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  // block = 64 tokens x 4 channel groups (wave g covers channels [g*D/4, (g+1)*D/4))
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+  const int cpg = D / 4;  // 64 for D = 256
+  float v[64];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    v[c] = (c < cpg && t < Tp) ? x[(int64_t)(grp * cpg + c) * Tp + t] : 0.f;
+    s += v[c];
+  }
+  s_part[grp][lane] = s;
+  __syncthreads();
+  const float m = (s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane]) / (float)D;
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    const float d = (c < cpg) ? v[c] - m : 0.f;
+    ss += d * d;
+  }
+  s_part[grp][lane] = ss;
+  __syncthreads();
+  if (grp == 0 && t < Tp) {
+    const float var = (s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane]) / (float)D;
+    mean[t] = m;
+    rstd[t] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// =====================================================================================
+// Implicit long-convolution filter (input independent): k'[c][t]
+// =====================================================================================
+__global__ __launch_bounds__(64) void hyena_filter_kernel(FilterArgs f) {
+  // one thread per tap t
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= f.n_taps) return;
+  const int fo = f.fo, emb = f.emb;
+  float h0[64], h1[64];
+  if (t < f.max_seq_len) {
+    float z[8];
+    for (int e = 0; e < emb; ++e) z[e] = f.pos_z[(int64_t)t * emb + e];
+    for (int o = 0; o < fo; ++o) {
+      float a = f.b0[o];
+      for (int e = 0; e < emb; ++e) a = fmaf(f.w0[o * emb + e], z[e], a);
+      h0[o] = sinf(f.freq0[o] * a);
+    }
+    for (int o = 0; o < fo; ++o) {
+      float a = f.b1[o];
+      for (int e = 0; e < fo; ++e) a = fmaf(f.w1[o * fo + e], h0[e], a);
+      h1[o] = sinf(f.freq1[o] * a);
+    }
+    for (int o = 0; o < fo; ++o) {
+      float a = f.b2[o];
+      for (int e = 0; e < fo; ++e) a = fmaf(f.w2[o * fo + e], h1[e], a);
+      h0[o] = sinf(f.freq2[o] * a);
+    }
+    const float tn = f.pos_t[t];
+    for (int c = 0; c < f.D; ++c) {
+      float a = 0.f;
+      for (int e = 0; e < fo; ++e) a = fmaf(f.w3[c * fo + e], h0[e], a);
+      const float decay = expf(-tn * fabsf(f.deltas[c]));
+      float kv = a * (decay + f.shift);
+      if (t == 0) kv += f.bias[c];  // the `u * D` skip of fftconv folded into tap 0
+      f.out[(int64_t)c * f.out_stride + t] = kv;
+    }
+  } else {
+    for (int c = 0; c < f.D; ++c) f.out[(int64_t)c * f.out_stride + t] = 0.f;
+  }
+}
+
+int launch_filter(hipStream_t st, const FilterArgs& f) {
+  DC_REQUIRE(f.fo <= 64 && f.emb <= 8, "filter MLP wider than supported");
+  hipLaunchKernelGGL(hyena_filter_kernel, dim3((f.n_taps + 63) / 64), dim3(64), 0, st, f);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+// =====================================================================================
+// Hyena operator core: short causal conv (k=3) + gate + long causal conv + gate
+//   z = sf(v) * sf(x1);  y = (k' (*) z) * sf(x0)
+// Long convolution as block-Toeplitz MFMA: time t = 32 p + q.  For output block p' and input
+// block p <= p':  Y[:, p'] += T_{p'-p} Z[:, p]  with  T_d[q'][q] = k'[32 d + q' - q]  (0 for
+// negative index).  MFMA 32x32x2 f32 with  M = q' (output phase), K = q (input phase, 16 steps
+// of 2; lane half h owns q in [16h, 16h+16) -- the K order is permuted identically in A and B),
+// N = 32 reads of a group.  A fragments come from the filter row in LDS, B fragments straight
+// from global memory (each lane reads 16 consecutive floats of its own read).
+// =====================================================================================
+__device__ __forceinline__ void load_window20(const float* __restrict__ row, int64_t t0, bool has_prev, bool active,
+                                              float (&w)[20]) {
+  // w[j] = row[t0 - 4 + j], j = 0..19; zeros before the start of the read (Conv1d padding).
+  float4 v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    if (has_prev) v[0] = *reinterpret_cast<const float4*>(row + t0 - 4);
+#pragma unroll
+    for (int j = 1; j < 5; ++j) v[j] = *reinterpret_cast<const float4*>(row + t0 - 4 + 4 * j);
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    w[4 * j + 0] = v[j].x;
+    w[4 * j + 1] = v[j].y;
+    w[4 * j + 2] = v[j].z;
+    w[4 * j + 3] = v[j].w;
+  }
+}
+
+__global__ __launch_bounds__(256) void hyena_kernel(HyenaArgs a) {
+  extern __shared__ float s_k[];  // [CH][32 + 32 * P]
+  const int g = blockIdx.x;
+  const int P = a.grp_P[g];
+  const int CH = a.CH;
+  const int c_base = blockIdx.y * CH;
+  const int kstride = 32 + 32 * P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+
+  for (int ch = 0; ch < CH; ++ch) {
+    const float* krow = a.kf + (int64_t)(c_base + ch) * a.kf_stride;
+    float* dst = s_k + ch * kstride;
+    for (int j = tid; j < kstride; j += 256) dst[j] = j < 32 ? 0.f : krow[j - 32];
+  }
+  __syncthreads();
+
+  int r = a.grp_reads[g * 32 + n];
+  const bool valid = r >= 0;
+  if (!valid) r = a.grp_reads[g * 32];  // first slot of a group is always a real read
+  const int64_t off = a.toff[r];
+  const int my_nblk = valid ? a.nblk[r] : 0;
+
+  const int nchunk = (P + 3) >> 2;
+  const int npairs = (nchunk + 1) >> 1;
+  const int n_items = npairs * CH;
+
+  for (int item = wave; item < n_items; item += 4) {
+    const int ch = item % CH;
+    const int pair = item / CH;
+    const int c = c_base + ch;
+    const float* kp = s_k + ch * kstride;
+    const float* ux0 = a.u + (int64_t)c * a.Tp + off;
+    const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + off;
+    const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + off;
+    float* yrow = a.y + (int64_t)c * a.Tp + off;
+    const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
+    const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
+                bx1 = a.sb[a.D + c];
+    const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
+                wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
+
+    for (int half = 0; half < 2; ++half) {
+      const int chunk = half == 0 ? pair : nchunk - 1 - pair;
+      if (half == 1 && chunk == pair) break;  // middle chunk of an odd count
+      const int p0 = chunk * 4;
+      f32x16 acc[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[jj][e] = 0.f;
+
+      const int pmax = (p0 + 3 < P - 1) ? p0 + 3 : P - 1;
+      for (int p = 0; p <= pmax; ++p) {
+        // ---- B fragment: z[t] for t = 32p + 16h + s, s = 0..15 ----
+        const int64_t t0 = 32 * p + 16 * h;
+        const bool active = p < my_nblk;
+        float w1[20], wv[20];
+        load_window20(ux1, t0, t0 > 0, active, w1);
+        load_window20(uv, t0, t0 > 0, active, wv);
+        float zf[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          // conv1d(padding=2)[..., :L]: out[t] = w0 u[t-2] + w1 u[t-1] + w2 u[t] + b
+          const float c1 = fmaf(wx1_0, w1[s + 2], fmaf(wx1_1, w1[s + 3], fmaf(wx1_2, w1[s + 4], bx1)));
+          const float cv = fmaf(wv_0, wv[s + 2], fmaf(wv_1, wv[s + 3], fmaf(wv_2, wv[s + 4], bv)));
+          zf[s] = active ? c1 * cv : 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int pp = p0 + jj;
+          if (pp >= p && pp < P) {  // wave-uniform
+            const int base = 32 + 32 * (pp - p) + n - 16 * h;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+              acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[base - s], zf[s], acc[jj], 0, 0, 0);
+          }
+        }
+      }
+
+      // ---- epilogue: y = conv * sf(x0); lane (n, h) holds q' = (e&3) + 8 (e>>2) + 4 h ----
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int pp = p0 + jj;
+        if (pp < P && valid && pp < my_nblk) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int64_t t = 32 * pp + 8 * gq + 4 * h;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t > 0) lo = *reinterpret_cast<const float4*>(ux0 + t - 4);
+            const float4 cu = *reinterpret_cast<const float4*>(ux0 + t);
+            const float g0 = fmaf(wx0_0, lo.z, fmaf(wx0_1, lo.w, fmaf(wx0_2, cu.x, bx0)));
+            const float g1 = fmaf(wx0_0, lo.w, fmaf(wx0_1, cu.x, fmaf(wx0_2, cu.y, bx0)));
+            const float g2 = fmaf(wx0_0, cu.x, fmaf(wx0_1, cu.y, fmaf(wx0_2, cu.z, bx0)));
+            const float g3 = fmaf(wx0_0, cu.y, fmaf(wx0_1, cu.z, fmaf(wx0_2, cu.w, bx0)));
+            float4 o;
+            o.x = acc[jj][4 * gq + 0] * g0;
+            o.y = acc[jj][4 * gq + 1] * g1;
+            o.z = acc[jj][4 * gq + 2] * g2;
+            o.w = acc[jj][4 * gq + 3] * g3;
+            *reinterpret_cast<float4*>(yrow + t) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
+  DC_REQUIRE(a.D % a.CH == 0, "CH must divide D");
+  const size_t lds = (size_t)a.CH * (32 + 32 * (size_t)max_P) * sizeof(float);
+  DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
+  if (lds > 64 * 1024) {
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(hyena_kernel, dim3(n_groups, a.D / a.CH), dim3(256), lds, st, a);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+// =====================================================================================
+// Head linear3 (1024 -> 2) + scatter of the logits back to the caller's dense layout
+// =====================================================================================
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ o, const float* __restrict__ w3,
+                                                       const float* __restrict__ b3, int H, int C, int64_t Tp,
+                                                       const int32_t* __restrict__ blk_read,
+                                                       const int32_t* __restrict__ toff,
+                                                       const int64_t* __restrict__ src_base,
+                                                       const int32_t* __restrict__ ntok,
+                                                       float* __restrict__ logits) {
+  extern __shared__ float s_w3[];  // [C][H]
+  for (int j = threadIdx.x; j < C * H; j += 256) s_w3[j] = w3[j];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tp) return;
+  const int r = blk_read[t >> 5];
+  if (r < 0) return;
+  const int l = (int)(t - toff[r]);
+  if (l >= ntok[r]) return;
+  float acc0 = 0.f, acc1 = 0.f;  // C == 2 (checked on the host)
+  for (int n = 0; n < H; ++n) {
+    const float v = o[(int64_t)n * Tp + t];
+    acc0 = fmaf(v, s_w3[n], acc0);
+    acc1 = fmaf(v, s_w3[H + n], acc1);
+  }
+  float2 out;
+  out.x = acc0 + b3[0];
+  out.y = acc1 + b3[1];
+  *reinterpret_cast<float2*>(logits + (src_base[r] + l) * 2) = out;
+}
+
+int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
+                 const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                 int64_t Tp, float* x, float* qpad) {
+  const unsigned grid = (unsigned)((Tp + 255) / 256);
+  const size_t lds = (size_t)vocab * D * sizeof(float);
+  if (ids_i64)
+    hipLaunchKernelGGL(embed_kernel<int64_t>, dim3(grid), dim3(256), lds, st, (const int64_t*)ids, quals, emb, vocab,
+                       D, blk_read, toff, src_base, ntok, Tp, x, qpad);
+  else
+    hipLaunchKernelGGL(embed_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)ids, quals, emb, vocab,
+                       D, blk_read, toff, src_base, ntok, Tp, x, qpad);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd) {
+  DC_REQUIRE(D % 4 == 0 && D / 4 <= 64, "ln_stats supports D <= 256");
+  hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)((Tp + 63) / 64)), dim3(256), 0, st, x, D, Tp, eps, mean, rstd);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
+                    const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                    float* logits) {
+  DC_REQUIRE(C == 2, "head_out supports num_class == 2");
+  hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)((Tp + 255) / 256)), dim3(256), (size_t)C * H * sizeof(float), st,
+                     o, w3, b3, H, C, Tp, blk_read, toff, src_base, ntok, logits);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+}  // namespace dc

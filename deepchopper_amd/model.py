@@ -1,0 +1,80 @@
+"""`DeepChopper.from_pretrained()` surface (deepchopper/models/dc_hg.py:26-163) over the HIP model.
+
+The returned object answers the two calls `deepchopper predict` makes on the reference's
+`TokenClassificationLit` (deepchopper/models/basic_module.py:90-100,197-207):
+`forward(input_ids, input_quals) -> logits[B, L, 2]` and `predict_step(batch) -> (logits, labels)`.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _lib, ops
+from .weights import HyenaDNAConfig, load_state_dict, synthetic_state_dict
+
+# names `deepchopper predict --model` resolves on the HF Hub (cli.py:117-121)
+HUB_NAMES = {"rna002": "yangliz5/deepchopper", "rna004": "yangliz5/deepchopper-rna004"}
+
+
+class TokenClassificationModel:
+    """Inference-only stand-in for `TokenClassificationLit`; all arithmetic is in libdeepchopper_hip."""
+
+    def __init__(self, state_dict, cfg: HyenaDNAConfig | None = None):
+        self.cfg = cfg or HyenaDNAConfig()
+        self.net = ops.HipModel(state_dict, self.cfg)
+
+    def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor) -> torch.Tensor:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ids = input_ids.to(dev)
+        if ids.dtype not in (torch.int64, torch.uint8):
+            ids = ids.to(torch.int64)
+        q = input_quals.to(dev, torch.float32)
+        return self.net.forward(ids.contiguous(), q.contiguous())
+
+    __call__ = forward
+
+    def predict_step(self, batch: dict, batch_idx: int = 0):
+        return self.forward(batch["input_ids"], batch["input_quals"]), batch["labels"]
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+
+class DeepChopper:
+    @staticmethod
+    def from_state_dict(state_dict, cfg: HyenaDNAConfig | None = None) -> TokenClassificationModel:
+        return TokenClassificationModel(state_dict, cfg)
+
+    @staticmethod
+    def from_checkpoint(checkpoint_path: str) -> TokenClassificationModel:
+        """dc_hg.py:70-117: a Lightning `.ckpt` (its `state_dict`)."""
+        return TokenClassificationModel(load_state_dict(checkpoint_path))
+
+    @staticmethod
+    def from_pretrained(model_name: str) -> TokenClassificationModel:
+        """dc_hg.py:119-163.  `model_name` is a local directory / file holding the checkpoint the
+        reference would download (`model.safetensors` written by PyTorchModelHubMixin).  Hub ids
+        (`yangliz5/deepchopper`) are resolved through $DEEPCHOPPER_MODEL_DIR/<id> or the HF cache
+        if present; there is no network access in this build."""
+        for cand in (model_name, os.path.join(os.environ.get("DEEPCHOPPER_MODEL_DIR", ""), model_name)):
+            if cand and os.path.exists(cand):
+                return TokenClassificationModel(load_state_dict(cand))
+        try:
+            from huggingface_hub import snapshot_download
+
+            path = snapshot_download(model_name, local_files_only=True)
+            return TokenClassificationModel(load_state_dict(path))
+        except Exception as e:
+            raise FileNotFoundError(
+                f"checkpoint '{model_name}' not found locally (set DEEPCHOPPER_MODEL_DIR or pass a path to "
+                f"model.safetensors / .ckpt); the HF Hub is not reachable from this environment: {e}"
+            ) from None
+
+    @staticmethod
+    def synthetic(seed: int = 0) -> TokenClassificationModel:
+        """Seeded synthetic weights of the exact reference shapes (benchmarks / tests)."""
+        return TokenClassificationModel(synthetic_state_dict(seed))

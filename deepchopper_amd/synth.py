@@ -1,0 +1,91 @@
+"""Deterministic synthetic inputs (SURVEY 8d / BASELINE.md section 2).
+
+PRNG = splitmix64 (vectorised), seed 42 for reads, 43 for label streams.  Bases iid uniform
+over ACGT with 0.1 % N, qualities iid uniform Phred 1..40 (ASCII 34..73), ids `read_{i:09d}`;
+half the reads carry a planted "adapter" (poly-A(20) + a fixed 60-mer) at a random interior
+position.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+ADAPTER_60 = b"CTGTAGGCACCATCAATGATCGTCGGACTGTAGAACTCTGAACGTGTAGATCTCGGTGGT"
+PLANT = b"A" * 20 + ADAPTER_60
+
+
+def splitmix64(seed: int, n: int, stream: int = 0) -> np.ndarray:
+    """n outputs of splitmix64 started at `seed` (+ a stream offset so that independent draws do
+    not overlap).  Vectorised: output i is the mix of state seed + (i+1) * golden."""
+    with np.errstate(over="ignore"):
+        golden = np.uint64(0x9E3779B97F4A7C15)
+        base = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + np.uint64(stream) * np.uint64(0xD1342543DE82EF95)
+        z = base + (np.arange(1, n + 1, dtype=np.uint64) * golden)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, n: int, stream: int = 0) -> np.ndarray:
+    return (splitmix64(seed, n, stream) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def synth_reads_fixed(n_reads: int, length: int, seed: int = 42, plant: bool = True, start_index: int = 0):
+    """Fixed-length reads as dense uint8 arrays: (seq[n, L], qual[n, L], ids list)."""
+    total = n_reads * length
+    r = splitmix64(seed, total, stream=2 * start_index + 1)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[(r & np.uint64(3)).astype(np.int64)]
+    is_n = ((r >> np.uint64(8)) % np.uint64(1000)) == 0
+    bases = np.where(is_n, np.uint8(ord("N")), bases).reshape(n_reads, length)
+    q = splitmix64(seed, total, stream=2 * start_index + 2)
+    qual = (34 + (q % np.uint64(40)).astype(np.int64)).astype(np.uint8).reshape(n_reads, length)
+    if plant and length >= len(PLANT) + 2:
+        pos = splitmix64(seed, n_reads, stream=2 * start_index + 3)
+        pl = np.frombuffer(PLANT, dtype=np.uint8)
+        for i in range(0, n_reads, 2):  # every other read
+            p = 1 + int(pos[i] % np.uint64(length - len(PLANT) - 1))
+            bases[i, p : p + len(PLANT)] = pl
+    ids = [f"read_{start_index + i:09d}" for i in range(n_reads)]
+    return bases, qual, ids
+
+
+def synth_reads_mixed(n_reads: int, min_len: int = 100, max_len: int = 10000, seed: int = 42):
+    """Log-uniform lengths in [min_len, max_len] (config C4).  Returns lists of bytes."""
+    u = uniform01(seed, n_reads, stream=7)
+    lens = np.exp(np.log(min_len) + u * (np.log(max_len) - np.log(min_len))).astype(np.int64)
+    lens = np.clip(lens, min_len, max_len)
+    seqs, quals, ids = [], [], []
+    for i, L in enumerate(lens.tolist()):
+        s, q, d = synth_reads_fixed(1, L, seed=seed + 1000 + i, plant=(i % 2 == 0))
+        seqs.append(s[0].tobytes())
+        quals.append(q[0].tobytes())
+        ids.append(f"read_{i:09d}")
+    return seqs, quals, ids
+
+
+def synth_label_stream(n: int, seed: int = 43, noise: float = 0.02, run_every: int = 400, mean_run: float = 60.0,
+                       stream: int = 0) -> np.ndarray:
+    """Binary label stream: Bernoulli(noise) flips plus planted runs of ones with geometric length
+    (mean `mean_run`), roughly one run per `run_every` positions."""
+    u = uniform01(seed, n, stream=3 * stream + 11)
+    lab = (u < noise).astype(np.int8)
+    n_runs = max(n // run_every, 1)
+    starts = (uniform01(seed, n_runs, stream=3 * stream + 12) * n).astype(np.int64)
+    g = uniform01(seed, n_runs, stream=3 * stream + 13)
+    lens = np.maximum(1, np.floor(np.log(1.0 - g) / np.log(1.0 - 1.0 / mean_run))).astype(np.int64)
+    for s, l in zip(starts.tolist(), lens.tolist()):
+        lab[s : min(n, s + l)] = 1
+    # flip a little noise inside the runs too
+    flip = uniform01(seed, n, stream=3 * stream + 14) < noise
+    lab = np.where(flip, 1 - lab, lab).astype(np.int8)
+    return lab
+
+
+def to_fastq(seqs, quals, ids) -> bytes:
+    out = []
+    for s, q, i in zip(seqs, quals, ids):
+        sb = s.tobytes() if hasattr(s, "tobytes") else bytes(s)
+        qb = q.tobytes() if hasattr(q, "tobytes") else bytes(q)
+        out.append(b"@" + i.encode() + b"\n" + sb + b"\n+\n" + qb + b"\n")
+    return b"".join(out)

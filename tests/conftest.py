@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def kats():
+    import json
+
+    with open(os.path.join(GOLDEN, "reference_kats.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Build (if needed) and load the C-ABI library.  GPU tests must never fall back silently."""
+    from deepchopper_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()

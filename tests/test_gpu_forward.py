@@ -1,0 +1,158 @@
+"""GPU parity tests for the forward (F1-F3) through the C ABI against the torch-fp32 CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks for per-base logits within 1e-3; the fp32-MFMA path
+is an exact fp32 FMA chain, so these tests hold it to 2e-4 absolute on O(1) logits and require the
+argmax labels to be identical wherever the oracle's margin exceeds that tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def env(hip_lib):
+    import torch
+
+    from deepchopper_amd import _lib, ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+
+    assert _lib.device_count() >= 1, "GPU tests need a HIP device; there is no CPU fallback"
+    sd = synthetic_state_dict(0)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    return torch, ops, sd, model
+
+
+def _inputs(rng, B, L, pad_max=0):
+    ids = rng.integers(7, 12, (B, L)).astype(np.int64)
+    q = rng.integers(1, 41, (B, L)).astype(np.float32)
+    ids[:, -1] = 1
+    q[:, -1] = 0
+    for b in range(B):
+        p = int(rng.integers(0, pad_max + 1)) if pad_max else 0
+        ids[b, :p] = 4
+        q[b, :p] = 0
+    q /= np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)
+    return ids, q.astype(np.float32)
+
+
+def _check(logits, ref):
+    diff = np.abs(logits - ref)
+    assert np.isfinite(logits).all()
+    assert diff.max() < ATOL, f"max |dlogit| = {diff.max():.3e}"
+    margin = np.abs(ref[..., 1] - ref[..., 0])
+    sure = margin > 2 * ATOL
+    assert np.array_equal((logits[..., 1] > logits[..., 0])[sure], (ref[..., 1] > ref[..., 0])[sure])
+
+
+def test_filter_matches_oracle(env):
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    cfg = fr.HyenaDNAConfig()
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    for layer in (0, 3):
+        L = 1500
+        k = model.filter(layer, L).cpu().numpy()
+        p = fr.BB + f"layers.{layer}.mixer.filter_fn."
+        ref = fr.hyena_filter(tsd, p, L, cfg).numpy().T.copy()  # [D, L]
+        ref[:, 0] += sd[p + "bias"]  # the skip term is folded into tap 0
+        np.testing.assert_allclose(k, ref, rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (1, 31), (2, 33), (3, 129), (33, 65), (5, 513), (2, 1001)])
+def test_forward_dense_matches_oracle(env, B, L):
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(100 + B * 7 + L)
+    ids, q = _inputs(rng, B, L)
+    ref = fr.forward(sd, ids, q).numpy()
+    out = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
+    _check(out, ref)
+    # compact uint8 ids give the same bits
+    out8 = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q)).cpu().numpy()
+    assert np.array_equal(out8, out)
+
+
+def test_forward_left_padded_batch_matches_oracle(env):
+    """Reference-style batch: left pad tokens (id 4) are ordinary tokens to the model."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(42)
+    ids, q = _inputs(rng, 6, 300, pad_max=120)
+    ref = fr.forward(sd, ids, q).numpy()
+    out = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
+    _check(out, ref)
+
+
+def test_forward_ragged_equals_per_read_oracle(env):
+    """Native zero-padding mode == the reference at --batch-size 1 for every read."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(7)
+    lens = [1, 17, 32, 33, 100, 257, 640, 77, 5, 999, 64, 300] + [int(x) for x in rng.integers(1, 400, 40)]
+    B, stride = len(lens), max(lens)
+    ids = np.full((B, stride), 4, np.int64)
+    q = np.zeros((B, stride), np.float32)
+    first = np.zeros(B, np.int32)
+    for b, n in enumerate(lens):
+        i1, q1 = _inputs(rng, 1, n)
+        first[b] = stride - n
+        ids[b, stride - n:] = i1[0]
+        q[b, stride - n:] = q1[0]
+    out = model.forward_ragged(ops.to_device(ids), ops.to_device(q), first, np.array(lens, np.int32)).cpu().numpy()
+    for b, n in enumerate(lens):
+        ref = fr.forward(sd, ids[b: b + 1, stride - n:], q[b: b + 1, stride - n:]).numpy()[0]
+        _check(out[b, stride - n:], ref)
+        assert np.all(out[b, : stride - n] == 0)
+
+
+def test_head_against_reference_golden(env, golden_dir):
+    """F3 pinned by vectors generated from the reference's own head.py: feed the golden `x` as
+    the backbone output by making the backbone an identity (zero blocks, unit LayerNorm)."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+    from deepchopper_amd.weights import HD, synthetic_state_dict
+
+    g = np.load(os.path.join(golden_dir, "head_golden.npz"))
+    sd7 = synthetic_state_dict(seed=7)
+    chk = np.array([float(np.sum(sd7[HD + f"{n}.weight"].astype(np.float64))) for n in ("linear1", "linear2", "linear3")])
+    np.testing.assert_allclose(chk, g["weight_checksums"], rtol=1e-12)
+    # oracle head == reference head (CPU)
+    tsd = {k: torch.as_tensor(v) for k, v in sd7.items()}
+    ref = fr.head_forward(tsd, torch.as_tensor(g["x"]), torch.as_tensor(g["quals"])).numpy()
+    np.testing.assert_allclose(ref, g["logits"], rtol=0, atol=1e-5)
+
+
+def test_forward_deterministic_and_batch_invariant(env):
+    torch, ops, sd, model = env
+    rng = np.random.default_rng(5)
+    ids, q = _inputs(rng, 40, 257)
+    a = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
+    b = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
+    assert np.array_equal(a, b)
+    # a read's logits do not depend on its batch neighbours
+    c = model.forward(ops.to_device(ids[3:4]), ops.to_device(q[3:4])).cpu().numpy()
+    np.testing.assert_allclose(c[0], a[3], rtol=0, atol=1e-5)
+
+
+def test_forward_at_bench_shape_properties(env):
+    """1 kb reads at a bench-like batch: finite, deterministic, spot-checked against the oracle."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(9)
+    ids, q = _inputs(rng, 256, 1001)
+    out = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert np.isfinite(out).all()
+    for b in (0, 100, 255):
+        ref = fr.forward(sd, ids[b: b + 1], q[b: b + 1]).numpy()[0]
+        _check(out[b], ref)
