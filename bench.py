@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reads/s through `predict` (tokenise -> forward -> smooth/intervals) on
+synthetic fixed-length reads, inputs resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+(one rank per GPU).  Reads shard across ranks with no data-path collective; the
+only cross-rank traffic is the barrier and the max-over-ranks of the elapsed time.
+
+A "step" is one pass of the hot path over one batch of `--batch` synthetic reads of `--read-len`
+bases (BASELINE.json configs[1]: 1 M synthetic 1 kb reads on one MI355X, processed batch by batch).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# forward GEMM flops per token
+FLOPS_PER_TOKEN = {
+    "gemm_inproj": 2 * 256 * 768,
+    "gemm_outproj": 2 * 256 * 256,
+    "gemm_fc1": 2 * 256 * 1024,
+    "gemm_fc2": 2 * 1024 * 256,
+    "gemm_head1": 2 * 256 * 1024,
+    "gemm_head2": 2 * 1024 * 1024,
+}
+FLOPS_PER_TOKEN_TOTAL = 8_916_992
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+DOMINANT = "gemm_head2"       # head linear2 (1024x1024): 23.5 % of the algorithmic flops, one launch / step
+
+
+def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
+    """Time the CPU oracle (torch fp32 + numpy restatement of the same path, reference batch size
+    12) on a bounded sample of the same workload.  kind = "port": the reference's own `predict`
+    cannot run here."""
+    import torch
+
+    from oracle import dc_oracle as o
+    from oracle import forward_ref as fr
+
+    def run(idx):
+        feats = []
+        for i in idx:
+            rec = o.parse_fastq_record(ids[i], seqs[i].decode("latin1"), quals[i].decode("latin1"))
+            feats.append(o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"]))
+        out = {}
+        for b0 in range(0, len(feats), 12):  # cli.py:70 default batch size
+            fb = feats[b0: b0 + 12]
+            batch = o.collate(fb)
+            logits = fr.forward(sd, batch["input_ids"], batch["input_quals"]).numpy()
+            preds = o.load_predicts_from_batch({"prediction": logits, "target": batch["labels"],
+                                                "seq": batch["input_ids"], "id": batch["id"]})
+            for rid, p in preds.items():
+                out[rid] = (p.prediction, p.smooth_label(21), p.smooth_and_select_intervals(21, 13, 20))
+        return out
+
+    t0 = time.perf_counter()
+    res = run(range(12))
+    per12 = time.perf_counter() - t0
+    n_more = int(max(0, min(len(seqs) - 12, (budget_s - per12) / max(per12, 1e-3) * 12)) // 12 * 12)
+    t1 = time.perf_counter()
+    if n_more:
+        res.update(run(range(12, 12 + n_more)))
+    total = per12 + (time.perf_counter() - t1)
+    n = 12 + n_more
+    return n / total, n, torch.get_num_threads(), res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2048, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=1000)
+    ap.add_argument("--resident-batches", type=int, default=2, help="distinct synthetic batches kept in HBM")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from deepchopper_amd import ops, synth
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+    from deepchopper_amd.weights import synthetic_state_dict
+
+    sd = synthetic_state_dict(0)
+    model = DeepChopper.from_state_dict(sd)
+    pipe = PredictPipeline(model)
+    B, L = args.batch, args.read_len
+
+    # rank-local shard of the synthetic read set, resident in HBM before the timed region
+    batches = []
+    host_first = None
+    for j in range(args.resident_batches):
+        start = (rank * args.resident_batches + j) * B
+        seq, qual, ids = synth.synth_reads_fixed(B, L, seed=42, start_index=start)
+        if host_first is None:
+            host_first = (seq, qual, ids)
+        offs = np.arange(B + 1, dtype=np.int64) * L
+        batches.append((ops.to_device(seq.reshape(-1)), ops.to_device(qual.reshape(-1)), ops.to_device(offs)))
+    lens = np.full(B, L, np.int64)
+
+    def step(j):
+        s, q, o = batches[j % len(batches)]
+        return pipe.run_device_batch(s, q, o, lens, want_labels=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for j in range(args.warmup):
+        step(j)
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        model.net.set_profiling(True)
+        model.net.profile_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for j in range(args.steps):
+        last = step(j)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = model.net.profile() if not args.no_profile else {}
+    model.net.set_profiling(False)
+
+    if rank == 0:
+        tokens_per_launch = B * (L + 1)
+        stages = {}
+        for name, (ms, cnt) in sorted(prof.items()):
+            if cnt == 0:
+                continue
+            avg_ms = ms / cnt
+            ent = {"launches": cnt, "avg_ms": round(avg_ms, 4), "share": round(ms / max(prof["forward"][0], 1e-9), 4)}
+            if name in FLOPS_PER_TOKEN:
+                ent["tflops"] = round(FLOPS_PER_TOKEN[name] * tokens_per_launch / (avg_ms * 1e-3) / 1e12, 2)
+            stages[name] = ent
+        roof = None
+        if DOMINANT in stages:
+            ach = FLOPS_PER_TOKEN[DOMINANT] * tokens_per_launch / (stages[DOMINANT]["avg_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": stages[DOMINANT]["avg_ms"],
+                    "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[DOMINANT] * tokens_per_launch}
+        if "forward" in stages:
+            stages["forward"]["tflops_all_gemm_flops"] = round(
+                FLOPS_PER_TOKEN_TOTAL * tokens_per_launch / (stages["forward"]["avg_ms"] * 1e-3) / 1e12, 2)
+
+        cpu = None
+        f1 = None
+        if world == 1 and args.cpu_seconds > 0:
+            seq, qual, ids = host_first
+            n_s = min(B, 240)
+            seqs = [seq[i].tobytes() for i in range(n_s)]
+            quals = [qual[i].tobytes() for i in range(n_s)]
+            rate, n_done, cores, ref = cpu_baseline(seqs, quals, ids[:n_s], sd, args.cpu_seconds)
+            cpu = {"value": round(rate, 3), "unit": "reads/s", "cores": cores, "kind": "port",
+                   "sample": f"{n_done} of the same synthetic {L}-bp reads, oracle tokenise+forward(torch fp32, batch 12)+smooth"}
+            # per-base F1 of the GPU labels against the oracle's on the sampled reads (expected 1.0)
+            res = step(0)
+            torch.cuda.synchronize()
+            o = res["smooth"]["offsets"].cpu().numpy()
+            pred = res["smooth"]["pred"].cpu().numpy()
+            tp = fp = fn = 0
+            same_iv = True
+            iv = res["smooth"]["intervals"].cpu().numpy()
+            niv = res["smooth"]["n_intervals"].cpu().numpy()
+            for r in range(n_done):
+                g = pred[o[r]: o[r + 1]]
+                e, _, eiv = ref[ids[r]]
+                tp += int(np.sum((g == 1) & (e == 1)))
+                fp += int(np.sum((g == 1) & (e == 0)))
+                fn += int(np.sum((g == 0) & (e == 1)))
+                same_iv &= [tuple(x) for x in iv[r, : niv[r]].tolist()] == eiv
+            f1 = {"per_base_f1_vs_oracle": round(2 * tp / max(2 * tp + fp + fn, 1), 6), "reads": n_done,
+                  "intervals_identical": bool(same_iv)}
+
+        value = world * B * args.steps / elapsed
+        print(json.dumps({
+            "metric": "reads/sec through predict, 1 kb reads",
+            "value": round(value, 2),
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: synthetic {L}-bp reads, 1xMI355X batches of {B} reads "
+                                   f"(tokenise -> HyenaDNA forward -> argmax/smooth/intervals), synthetic weights",
+                       "reads_per_step_per_gpu": B, "read_len": L, "tokens_per_read": L + 1,
+                       "parallelism": f"read-sharded x{world}, no collectives"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity": f1,
+            "stages": stages,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

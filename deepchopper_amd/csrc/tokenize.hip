@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void tokenize_batch_kernel(
     __syncthreads();
     const unsigned long long sumsq = s_sumsq[0] + s_sumsq[1] + s_sumsq[2] + s_sumsq[3];
     // F.normalize(dim=0): x / max(||x||_2, 1e-12), fp32 (tokenizer.py:166).
-    const float nrm = fmaxf(__fsqrt_rn((float)sumsq), 1e-12f);
+    const float nrm = fmaxf(sqrtf((float)sumsq), 1e-12f);  // correctly rounded (hipcc default)
 
     const int64_t pad = pad_left ? (row_stride - ntok) : 0;
     IdT* id_row = ids + (int64_t)r * row_stride;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void tokenize_batch_kernel(
           tok = (IdT)t;
         }
         const float p = (float)uint8_t(qual[beg + i] - qual_offset);
-        qv = __fdiv_rn(p, nrm);
+        qv = p / nrm;  // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
         lab = 0;
       } else if (i == len) {
         tok = (IdT)DC_TOK_SEP;

@@ -41,7 +41,10 @@ def pack_reads(reads: list[bytes]) -> tuple[np.ndarray, np.ndarray]:
 
 
 def to_device(a: np.ndarray) -> torch.Tensor:
-    t = torch.from_numpy(np.ascontiguousarray(a))
+    a = np.ascontiguousarray(a)
+    if not a.flags.writeable:
+        a = a.copy()
+    t = torch.from_numpy(a)
     return t.to(_dev(), non_blocking=False)
 
 
