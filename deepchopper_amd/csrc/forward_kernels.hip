@@ -28,16 +28,37 @@ constexpr int G_BK = 32;
 
 __device__ __forceinline__ float gelu_tanh(float x) {
   // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  // == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 + one division
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float inner = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  const float u = k0 * (x + k1 * x * x * x);
+  return __fdividef(x, 1.0f + __expf(-2.0f * u));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
+#define DC_AS1 __attribute__((address_space(1)))
+#define DC_AS3 __attribute__((address_space(3)))
+
+// 16-byte direct-to-LDS load (LDS-DMA): lane l writes LDS bytes [lds_base + 16 l, +16); the LDS
+// destination is a wave-uniform byte address (M0), the global source is per lane.  Issued from
+// inline asm on purpose: hipcc does not count asm memory operations, so it does not drain vmcnt
+// before every ds_read of the same LDS array (it cannot tell the two buffers apart); completion is
+// waited for by hand (`s_waitcnt vmcnt(0)` + barrier) one phase before the buffer is read.
+__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+
 template <int EPI, bool LN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-  __shared__ float sA[2][G_BK][G_BN];
-  __shared__ float sB[2][G_BK][G_BT];
+  // one LDS object (a second __shared__ array next to an LDS-DMA target can make hipcc drain vmcnt early)
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * G_BK * G_BN];
+  float(*sA)[G_BK][G_BN] = reinterpret_cast<float(*)[G_BK][G_BN]>(smem);
+  float(*sB)[G_BK][G_BT] = reinterpret_cast<float(*)[G_BK][G_BT]>(smem + 2 * G_BK * G_BN);
 
   // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous
   // range of logical ids so that the N/128 blocks that share one token panel hit the same L2.
@@ -54,22 +75,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int64_t t_blk = tb * G_BT;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wt = wave & 1;
   const int i = lane & 31, h = lane >> 5;
 
-  // staging coordinates: 32 rows x 32 float4 per tile, 4 float4 per thread
-  const int ld_row = tid >> 5;        // 0..7 (+8 j)
-  const int ld_col = (tid & 31) * 4;  // float offset
-  const float* gA = g.Wt + (int64_t)ld_row * g.N + n_blk + ld_col;
-  const float* gB = g.X + (int64_t)ld_row * g.Tp + t_blk + ld_col;
-
-  float4 ra[4], rb[4];
+  // staging: a 32 x 128 fp32 tile = 16 wave-instructions of 1 KiB (2 rows each); wave w moves rows
+  // [8w, 8w+8) of both operands with 4 + 4 LDS-DMA loads per k-tile, no staging registers.
+  const float* gA = g.Wt + (int64_t)(8 * wave + h) * g.N + n_blk + 4 * i;
+  const float* gB = g.X + (int64_t)(8 * wave + h) * g.Tp + t_blk + 4 * i;
+  const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds_addr(&sA[0][8 * wave][0]));
+  const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds_addr(&sB[0][8 * wave][0]));
+  auto stage = [&](int buf, int kt) {
+    const float* pa = gA + (int64_t)kt * G_BK * g.N;
+    const float* pb = gB + (int64_t)kt * G_BK * g.Tp;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    ra[j] = *reinterpret_cast<const float4*>(gA + (int64_t)(8 * j) * g.N);
-    rb[j] = *reinterpret_cast<const float4*>(gB + (int64_t)(8 * j) * g.Tp);
-  }
+    for (int j = 0; j < 4; ++j) {
+      glds16(pa + (int64_t)(2 * j) * g.N, ldsA + (uint32_t)((buf * G_BK + 2 * j) * G_BN * 4));
+      glds16(pb + (int64_t)(2 * j) * g.Tp, ldsB + (uint32_t)((buf * G_BK + 2 * j) * G_BT * 4));
+    }
+  };
+
+  stage(0, 0);
 
   float rs[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f};
   if (LN) {
@@ -90,70 +117,84 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    *reinterpret_cast<float4*>(&sA[0][ld_row + 8 * j][ld_col]) = ra[j];
-    *reinterpret_cast<float4*>(&sB[0][ld_row + 8 * j][ld_col]) = rb[j];
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int nk = g.K / G_BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const float* pa = gA + (int64_t)(kt + 1) * G_BK * g.N;
-      const float* pb = gB + (int64_t)(kt + 1) * G_BK * g.Tp;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);  // lands in the other buffer while this one is consumed
+
+    const float* pA = &sA[cur][h][wn * 64 + i];
+    const float* pB = &sB[cur][h][wt * 64 + i];
+    float a[2][2], b[2][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ra[j] = *reinterpret_cast<const float4*>(pa + (int64_t)(8 * j) * g.N);
-        rb[j] = *reinterpret_cast<const float4*>(pb + (int64_t)(8 * j) * g.Tp);
-      }
+    for (int x = 0; x < 2; ++x) {
+      a[0][x] = pA[x * 32];
+      b[0][x] = pB[x * 32];
     }
 #pragma unroll
     for (int s = 0; s < G_BK / 2; ++s) {
-      const int kk = 2 * s + h;
-      float a[2], b[2];
+      const int c = s & 1;
+      float bb[2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = sA[cur][kk][wn * 64 + mi * 32 + i];
+      for (int ni = 0; ni < 2; ++ni) bb[ni] = LN ? fmaf(b[c][ni], rs[ni], nm[ni]) : b[c][ni];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], bb[0], acc[0][0], 0, 0, 0);
+      if (s + 1 < G_BK / 2) {  // next k-step's fragments fly behind this step's remaining three MFMAs
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        b[ni] = sB[cur][kk][wt * 64 + ni * 32 + i];
-        if (LN) b[ni] = fmaf(b[ni], rs[ni], nm[ni]);
+        for (int x = 0; x < 2; ++x) {
+          a[c ^ 1][x] = pA[(2 * (s + 1)) * G_BN + x * 32];
+          b[c ^ 1][x] = pB[(2 * (s + 1)) * G_BT + x * 32];
+        }
       }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], bb[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], bb[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], bb[1], acc[1][1], 0, 0, 0);
+      // pin the issue order: (LN fma x2) | MFMA | DS reads of step s+1 | MFMA x3
+      if (LN) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<float4*>(&sA[cur ^ 1][ld_row + 8 * j][ld_col]) = ra[j];
-        *reinterpret_cast<float4*>(&sB[cur ^ 1][ld_row + 8 * j][ld_col]) = rb[j];
-      }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // epilogue: C[n][t], n = row of the accumulator, t = lane column
+  // epilogue: C[n][t], n = accumulator row, t = lane column.  Accumulator register e of lane half h
+  // is row (e&3) + 8 (e>>2) + 4h of its 32x32 tile: the bias of 4 consecutive registers is one float4,
+  // and all residual loads of a tile are issued before the first use.
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
+  const int n0 = n_blk + wn * 64 + 4 * h;
+  float4 bv[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) bv[mi][q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+      const int64_t base = (int64_t)(n0 + mi * 32) * g.Tp + t;
+      float* cp = g.C + base;
+      float rv[16];
+      if (RES) {
+        const float* rp = g.R + base;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = rp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp];
+      }
       float qv = 0.f;
       if (EPI == EPI_BIAS_RELU_Q) qv = g.q[t];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = n_blk + wn * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int64_t idx = (int64_t)n * g.Tp + t;
-        float v = acc[mi][ni][e] + g.bias[n];
-        if (EPI == EPI_BIAS_RES) v += g.R[idx];
+        const float4 b4 = bv[mi][e >> 2];
+        const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
+        float v = acc[mi][ni][e] + bias;
+        if (EPI == EPI_BIAS_RES) v += rv[e];
         if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
-        if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;            // head.py:94,97
-        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + g.R[idx], 0.f);    // head.py:98
-        g.C[idx] = v;
+        if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
+        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + rv[e], 0.f);     // head.py:98
+        cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
       }
     }
   }
