@@ -127,9 +127,7 @@ def main():
         s, q, o = batches[j % len(batches)]
         return pipe.run_device_batch(s, q, o, lens, want_labels=True)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    from deepchopper_amd.sharding import dist_barrier as barrier, dist_max
 
     for j in range(args.warmup):
         step(j)
@@ -146,10 +144,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_max(elapsed, device="cuda")  # the slowest rank defines the job's time
 
     prof = model.net.profile() if not args.no_profile else {}
     model.net.set_profiling(False)

@@ -1,0 +1,106 @@
+"""`deepchopper predict` command line (deepchopper/cli.py:66-152) on the HIP hot path.
+
+    python -m deepchopper_amd.cli predict reads.fastq -g 1 -o predictions -b 12 -m /path/to/checkpoint
+
+Flags and defaults are the reference's (`--gpus/-g 0`, `--output/-o predictions`, `--batch-size/-b 12`,
+`--workers/-w 0`, `--model/-m rna002`, `--limit-batches`, `--max-sample`, `--verbose/-v`).  Differences:
+there is no CPU mode (`-g 0` is rejected: this build has no CPU fallback) and `-m` also accepts a local
+checkpoint path because the Hub is unreachable here.  Output: `{out}/0/{rank}_{batch}.pt` in the
+reference's CustomWriter format (callbacks.py:12-25), which the reference's `deepchopper chop`
+consumes unchanged; `--native` additionally writes per-read labels / intervals (`{rank}.intervals.tsv`).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+from .fastq import iter_fastq
+from .sharding import shard_range
+
+
+def _predict(args) -> int:
+    import torch
+
+    from . import _lib
+    from .model import HUB_NAMES, DeepChopper
+    from .predict import PredictPipeline, write_pt_batch
+
+    data_path = Path(args.data_path)
+    if not data_path.exists():
+        print(f"Error: Data path '{data_path}' does not exist.", file=sys.stderr)
+        return 1
+    if args.gpus < 1:
+        print("Error: deepchopper_amd runs only on the GPU (use --gpus 1..8); there is no CPU fallback.", file=sys.stderr)
+        return 1
+    _lib.require_gpu()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("Error: launch multi-GPU predict with `python -m torch.distributed.run --nproc-per-node N -m "
+              "deepchopper_amd.cli predict ...` (one process per GPU)", file=sys.stderr)
+        return 1
+    if args.batch_size % world != 0:  # only_fq.py:198-201
+        raise RuntimeError(f"Batch size ({args.batch_size}) is not divisible by the number of devices ({world}).")
+    torch.cuda.set_device(local_rank)
+    model_name = HUB_NAMES.get(args.model.lower(), args.model)
+    model = DeepChopper.from_pretrained(model_name)
+    pipe = PredictPipeline(model)
+    out_dir = Path(args.output or "predictions")
+    per_dev = args.batch_size // world
+    # whole-file record list (ids / offsets) so that ranks can take contiguous shards
+    records = list(iter_fastq(str(data_path), max_records=args.max_sample))
+    if not records:
+        raise ValueError(f"No valid records found in {data_path}")
+    lo, hi = shard_range(len(records), rank, world)
+    mine = records[lo:hi]
+    tsv = None
+    if args.native:
+        os.makedirs(out_dir / "0", exist_ok=True)
+        tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w")
+    n_batches = 0
+    for b0 in range(0, len(mine), per_dev):
+        if args.limit_batches is not None and n_batches >= args.limit_batches:
+            break
+        chunk = mine[b0: b0 + per_dev]
+        ids = [r[0] for r in chunk]
+        reads, res = pipe.predict_reads(ids, [r[1] for r in chunk], [r[2] for r in chunk],
+                                        reference_padding=not args.native)
+        write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
+        if tsv:
+            for r in reads:
+                tsv.write(f"{r['id']}\t{len(r['prediction'])}\t" + ",".join(f"{s}:{e}" for s, e in r["intervals"]) + "\n")
+        n_batches += 1
+    if tsv:
+        tsv.close()
+    logging.info("rank %d wrote %d batches for reads [%d, %d)", rank, n_batches, lo, hi)
+    return 0
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="deepchopper", description="DeepChopper (MI355X-native predict path)")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    p = sub.add_parser("predict", help="DeepChopper: predict the given dataset")
+    p.add_argument("data_path", help="Path to the dataset")
+    p.add_argument("--gpus", "-g", type=int, default=0, help="Number of GPUs to use")
+    p.add_argument("--output", "-o", default=None, help="Output path for predictions")
+    p.add_argument("--batch-size", "-b", type=int, default=12, help="Batch size")
+    p.add_argument("--workers", "-w", type=int, default=0, help="Number of workers (unused: tokenisation runs on the GPU)")
+    p.add_argument("--model", "-m", default="rna002", help="Model name (rna002, rna004) or a local checkpoint path")
+    p.add_argument("--limit-batches", type=int, default=None, help="Limit prediction batches")
+    p.add_argument("--max-sample", type=int, default=None, help="Maximum number of samples to process")
+    p.add_argument("--verbose", "-v", action="store_true", help="Enable verbose output")
+    p.add_argument("--native", action="store_true", help="zero-padding batches + per-read intervals TSV")
+    args = ap.parse_args(argv)
+    if args.verbose:
+        logging.basicConfig(level=logging.INFO, format="%(message)s")
+    return _predict(args)
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,159 @@
+"""CPU tests: the C-ABI library loads and exports every declared symbol, fails loudly without a
+GPU, and the host-side mirrors of the PyO3 helpers reproduce the reference's known answers."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from deepchopper_amd import _lib
+
+
+def test_library_exports_every_header_symbol(hip_lib):
+    syms = _lib.header_symbols()
+    assert len(syms) >= 20 and "dc_forward" in syms and "dc_tokenize_batch" in syms
+    for s in syms:
+        assert hasattr(hip_lib, s), f"{s} declared in include/deepchopper_hip.h but not exported"
+    # and every bound signature is declared in the header
+    assert set(_lib._SIGNATURES) <= set(syms)
+    assert hip_lib.dc_version() >= 100
+
+
+def test_no_gpu_fails_loudly(hip_lib):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.DeepChopperHipError):
+        _lib.require_gpu()
+    cfg = _lib.ModelConfig(d_model=256, d_inner=1024, n_layer=4, vocab=16, filter_order=64, emb_dim=5,
+                           short_filter_order=3, max_seq_len=32770, head_hidden=1024, num_class=2, gelu_tanh=1,
+                           ln_eps=1e-5, filter_shift=0.05)
+    w = _lib.ModelWeights()
+    h = ctypes.c_void_p()
+    rc = hip_lib.dc_model_create(ctypes.byref(cfg), ctypes.byref(w), ctypes.byref(h))
+    assert rc == 3 and b"no CPU fallback" in hip_lib.dc_last_error()
+
+
+def test_argument_validation_without_gpu(hip_lib):
+    rc = hip_lib.dc_tokenize_batch(None, None, None, None, 4, 100, 33, 10, 1, 1, None, None, None, None, None)
+    assert rc == 1 and b"null pointer" in hip_lib.dc_last_error()
+    assert hip_lib.dc_tokenize_batch(None, None, None, None, 0, 100, 33, 10, 1, 1, None, None, None, None, None) == 0
+    rc = hip_lib.dc_kmer_validate(None, 1, 1, 3, 40, b"ACGT", 4, 1)
+    assert rc == 1 and b"k must be" in hip_lib.dc_last_error()
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "deepchopper_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_host_helpers_match_reference_kats(kats):
+    from deepchopper_amd import rs_api as r
+
+    for c in kats["generate_kmers"]["cases"]:
+        assert r.generate_kmers(c["bases"], c["k"]) == c["expected"]
+    for c in kats["generate_kmers_table"]["cases"]:
+        assert r.generate_kmers_table(c["bases"], c["k"]) == c["expected"]
+    for c in kats["to_kmer_target_region"]["cases"]:
+        if "error" in c:
+            with pytest.raises(Exception, match=c["error"]):
+                r.to_kmer_target_region(c["start"], c["end"], c["k"], c["seq_len"])
+        else:
+            assert list(r.to_kmer_target_region(c["start"], c["end"], c["k"], c["seq_len"])) == c["expected"]
+    for c in kats["to_original_targtet_region"]["cases"]:
+        assert list(r.to_original_targtet_region(c["start"], c["end"], c["k"])) == c["expected"]
+    for c in kats["seq_to_kmers_and_offset"]["cases"]:
+        got = r.seq_to_kmers_and_offset(c["seq"], c["k"], c["overlap"])
+        assert len(got) == c["expected_len"] and [got[0][0], list(got[0][1])] == c["first"]
+        assert [got[1][0], list(got[1][1])] == c["second"]
+    with pytest.raises(Exception, match="shorter than the k-mer size"):
+        r.seq_to_kmers_and_offset("AT", 3, True)
+    for c in kats["vectorize_target"]["cases"]:
+        if "error" in c:
+            with pytest.raises(Exception, match=c["error"]):
+                r.vectorize_target(c["start"], c["end"], c["length"])
+        else:
+            assert r.vectorize_target(c["start"], c["end"], c["length"]) == c["expected"]
+    for c in kats["vectorize_targets"]["cases"]:
+        if "error" in c:
+            with pytest.raises(Exception, match=c["error"]):
+                r.vectorize_targets(c["targets"], c["length"])
+        else:
+            assert r.vectorize_targets(c["targets"], c["length"]) == c["expected"]
+    for c in kats["parse_target_from_id"]["cases"]:
+        assert r.parse_target_from_id(c["id"]) == [v for se in c["expected"] for v in se]
+    for c in kats["id_list2seq"]["cases"]:
+        assert r.id_list2seq(c["ids"]) == c["expected"]
+    for c in kats["remove_intervals_and_keep_left"]["cases"]:
+        parts, _ = r.remove_intervals_and_keep_left(c["seq"], [tuple(x) for x in c["intervals"]])
+        assert parts == c["expected"]
+    for c in kats["generate_unmaped_intervals"]["cases"]:
+        assert r.generate_unmaped_intervals([tuple(x) for x in c["intervals"]], c["total_length"]) == [tuple(x) for x in c["expected"]]
+    table = {v: k for k, v in r.generate_kmers_table("ATCGN", 3).items()}
+    assert r.kmerids_to_seq([table_id for table_id in (0, 1)], table) == "AAAT"
+    with pytest.raises(Exception, match="k-mer id is invalid"):
+        r.kmerids_to_seq([999], table)
+    assert r.kmers_to_seq(["ACG", "CGT", "GTA"]) == "ACGTA"
+    assert r.splite_qual_by_offsets([10, 20, 30, 41], [(0, 2), (2, 2), (1, 4)]) == [15, 0, 30]
+    assert r.default.QUAL_OFFSET == 33 and r.default.KMER_SIZE == 3 and r.default.BASES == "ATCGN"
+
+
+def test_id_encoding_and_sharding():
+    from deepchopper_amd.sharding import merge_by_id, shard_range
+    from deepchopper_amd.tokenizer import encode_ids_int8
+    from oracle import dc_oracle as o
+
+    row = encode_ids_int8("read_000000001", False)
+    assert row.dtype == np.int8 and row.shape == (256,)
+    assert np.array_equal(row.astype(np.int64), o.encode_id("read_000000001", False))
+    with pytest.raises(RuntimeError, match="int8"):
+        encode_ids_int8("x" * 128, False)
+    for n in (0, 1, 7, 8, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            rs = [shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    assert merge_by_id([{"a": 1}, {"b": 2}, {"a": 1}]) == {"a": 1, "b": 2}
+    with pytest.raises(ValueError):
+        merge_by_id([{"a": 1}, {"a": 2}])
+
+
+def test_fastq_reader(tmp_path, golden_dir):
+    from deepchopper_amd.fastq import iter_fastq
+    from deepchopper_amd import synth
+
+    recs = list(iter_fastq(os.path.join(golden_dir, "twenty_five_records.fq")))
+    assert len(recs) == 25 and all(len(s) == len(q) for _, s, q in recs)
+    seq, qual, ids = synth.synth_reads_fixed(5, 60, seed=42)
+    p = tmp_path / "x.fq.gz"
+    import gzip
+    with gzip.open(p, "wb") as fh:
+        fh.write(synth.to_fastq(seq, qual, ids))
+    got = list(iter_fastq(str(p)))
+    assert [g[0] for g in got] == ids and got[2][1] == seq[2].tobytes()
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r1\nACGT\n+\nII\n")
+    with pytest.raises(ValueError, match="length mismatch"):
+        list(iter_fastq(str(bad)))
+    empty = tmp_path / "e.fq"
+    empty.write_bytes(b"")
+    with pytest.raises(ValueError, match="No valid records"):
+        list(iter_fastq(str(empty)))
+
+
+def test_synthetic_generators_are_deterministic():
+    from deepchopper_amd import synth
+
+    a = synth.synth_reads_fixed(4, 200, seed=42)
+    b = synth.synth_reads_fixed(4, 200, seed=42)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert set(np.unique(a[0]).tolist()) <= set(b"ACGTN") and a[1].min() >= 34 and a[1].max() <= 73
+    assert synth.PLANT in a[0][0].tobytes() and synth.PLANT not in a[0][1].tobytes()
+    lab = synth.synth_label_stream(5000, seed=43)
+    assert lab.dtype == np.int8 and 0 < lab.mean() < 0.5
+    assert np.array_equal(lab, synth.synth_label_stream(5000, seed=43))
