@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct synthetic batches kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default=os.environ.get("DC_GEMM_MODE", "f32"))
     args = ap.parse_args()
 
     import torch
@@ -108,6 +109,7 @@ def main():
 
     sd = synthetic_state_dict(0)
     model = DeepChopper.from_state_dict(sd)
+    model.net.set_gemm_mode(args.gemm_mode)
     pipe = PredictPipeline(model)
     B, L = args.batch, args.read_len
 

@@ -12,7 +12,7 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeepchopper_hip.so")
+LIB_PATH = os.environ.get("DC_HIP_LIB") or os.path.join(_HERE, "lib", "libdeepchopper_hip.so")  # override: kernel A/B experiments
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "dc_forward_ragged": (C.c_int, [vp, vp, vp, i32, vp, i32, i64, C.POINTER(i32), C.POINTER(i32), vp]),
     "dc_model_device_bytes": (i64, [vp]),
     "dc_model_filter": (C.c_int, [vp, vp, i32, i32, vp]),
+    "dc_model_set_gemm_mode": (C.c_int, [vp, i32]),
     "dc_model_set_profiling": (C.c_int, [vp, i32]),
     "dc_model_profile_reset": (C.c_int, [vp]),
     "dc_model_profile_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),

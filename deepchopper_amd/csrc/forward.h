@@ -14,7 +14,8 @@ enum GemmEpilogue {
 };
 
 struct GemmArgs {
-  const float* Wt;    // [K][N]  pre-transposed (and LayerNorm-gamma folded) weights
+  const float* Wt;    // [K][N]  pre-transposed (and LayerNorm-gamma folded) weights (fp32 MFMA path)
+  const unsigned short* Wp;  // [3][K/8][N][8] bf16 planes h|m|l of Wt (bf16x6 path) or nullptr
   const float* X;     // [K][Tp]
   float* C;           // [N][Tp]
   const float* bias;  // [N]     (LayerNorm-beta folded)

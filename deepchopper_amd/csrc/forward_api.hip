@@ -22,6 +22,7 @@ struct LayerDev {
   float *Wt_out = nullptr, *b_out = nullptr;  // [D][D], [D]
   float *Wt_fc1 = nullptr, *b_fc1 = nullptr;  // [D][DI], [DI]  (norm2 folded)
   float *Wt_fc2 = nullptr, *b_fc2 = nullptr;  // [DI][D], [D]
+  unsigned short *Wp_in = nullptr, *Wp_out = nullptr, *Wp_fc1 = nullptr, *Wp_fc2 = nullptr;  // bf16 planes
   // implicit filter parameters (device copies, checkpoint layout)
   float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
         *fw2 = nullptr, *fb2 = nullptr, *fw3 = nullptr, *freq0 = nullptr, *freq1 = nullptr, *freq2 = nullptr,
@@ -42,6 +43,8 @@ struct dc_model {
   float* emb = nullptr;
   std::vector<LayerDev> layers;
   float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
+  unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
+  int gemm_mode = 0;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split on bf16 MFMA)
   int64_t kf_taps = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
@@ -86,6 +89,45 @@ int upload(dc_model* m, const std::vector<float>& h, float** out) {
   if (rc) return rc;
   DC_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   *out = (float*)p;
+  return DC_OK;
+}
+
+// bf16 round-to-nearest-even of an fp32 value (finite inputs)
+inline unsigned short bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_to_f32(unsigned short b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Error-free 3-way split of Wt[K][N] into planes [3][K/8][N][8] (h | m | l), uploaded as bf16.
+int upload_planes(dc_model* m, const std::vector<float>& Wt, int K, int N, unsigned short** out) {
+  std::vector<unsigned short> pl((size_t)3 * K * N);
+  const size_t plane = (size_t)K * N;
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) {
+      const float x = Wt[(size_t)k * N + n];
+      const unsigned short hh = bf16_rne(x);
+      const float r1 = x - bf16_to_f32(hh);
+      const unsigned short mm = bf16_rne(r1);
+      const float r2 = r1 - bf16_to_f32(mm);
+      const unsigned short ll = bf16_rne(r2);
+      const size_t idx = ((size_t)(k >> 3) * N + n) * 8 + (k & 7);
+      pl[idx] = hh;
+      pl[plane + idx] = mm;
+      pl[2 * plane + idx] = ll;
+    }
+  void* p = nullptr;
+  int rc = dev_alloc(m, pl.size() * sizeof(unsigned short), &p);
+  if (rc) return rc;
+  DC_HIP_CHECK(hipMemcpy(p, pl.data(), pl.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  *out = (unsigned short*)p;
   return DC_OK;
 }
 
@@ -214,10 +256,12 @@ struct ProfScope {
   }
 };
 
-int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, const float* X, float* C,
-             const float* bias, const float* R, const float* q, bool ln, int epi, int K, int N) {
+int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, const unsigned short* Wp,
+             const float* X, float* C, const float* bias, const float* R, const float* q, bool ln, int epi, int K,
+             int N) {
   GemmArgs g{};
   g.Wt = Wt;
+  g.Wp = m->gemm_mode == 1 ? Wp : nullptr;
   g.X = X;
   g.C = C;
   g.bias = bias;
@@ -371,7 +415,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D, 3 * D)))
+    if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, L.Wp_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D, 3 * D)))
       return rc;
     {
       HyenaArgs a{};
@@ -391,24 +435,24 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       ProfScope ps(m, st, "hyena");
       if ((rc = launch_hyena(st, a, m->n_groups, m->max_P))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, y, x, L.b_out, x, nullptr, false, EPI_BIAS_RES, D, D)))
+    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false, EPI_BIAS_RES, D, D)))
       return rc;
     {
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D, DI)))
+    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, L.Wp_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D, DI)))
       return rc;
-    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, hm, x, L.b_fc2, x, nullptr, false, EPI_BIAS_RES, DI, D)))
+    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, L.Wp_fc2, hm, x, L.b_fc2, x, nullptr, false, EPI_BIAS_RES, DI, D)))
       return rc;
   }
   {
     ProfScope ps(m, st, "ln_stats");
     if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
   }
-  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H)))
+  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, m->Wp_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H)))
     return rc;
-  if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU, H, H)))
+  if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU, H, H)))
     return rc;
   {
     ProfScope ps(m, st, "head_out");
@@ -439,6 +483,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   }
   dc_model* m = new dc_model();
   m->cfg = *cfg;
+  if (const char* e = getenv("DC_GEMM_MODE")) m->gemm_mode = (strcmp(e, "bf16x6") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
   const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;
@@ -456,17 +501,21 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     LayerDev& L = m->layers[li];
     fold_transpose(lw.in_proj_w, lw.in_proj_b, lw.norm1_w, lw.norm1_b, 3 * D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_in));
+    UP(upload_planes(m, Wt, D, 3 * D, &L.Wp_in));
     UP(upload(m, bo, &L.b_in));
     UP(upload_raw(m, lw.short_w, (size_t)3 * D * 3, &L.sw));
     UP(upload_raw(m, lw.short_b, (size_t)3 * D, &L.sb));
     fold_transpose(lw.out_proj_w, lw.out_proj_b, nullptr, nullptr, D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_out));
+    UP(upload_planes(m, Wt, D, D, &L.Wp_out));
     UP(upload(m, bo, &L.b_out));
     fold_transpose(lw.fc1_w, lw.fc1_b, lw.norm2_w, lw.norm2_b, DI, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_fc1));
+    UP(upload_planes(m, Wt, D, DI, &L.Wp_fc1));
     UP(upload(m, bo, &L.b_fc1));
     fold_transpose(lw.fc2_w, lw.fc2_b, nullptr, nullptr, D, DI, Wt, bo);
     UP(upload(m, Wt, &L.Wt_fc2));
+    UP(upload_planes(m, Wt, DI, D, &L.Wp_fc2));
     UP(upload(m, bo, &L.b_fc2));
     UP(upload_raw(m, lw.pos_z, (size_t)cfg->max_seq_len * emb, &L.pos_z));
     UP(upload_raw(m, lw.pos_t, (size_t)cfg->max_seq_len, &L.pos_t));
@@ -485,9 +534,11 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   }
   fold_transpose(w->head_w1, w->head_b1, w->ln_f_w, w->ln_f_b, H, D, Wt, bo);
   UP(upload(m, Wt, &m->Wt_l1));
+  UP(upload_planes(m, Wt, D, H, &m->Wp_l1));
   UP(upload(m, bo, &m->b_l1));
   fold_transpose(w->head_w2, w->head_b2, nullptr, nullptr, H, H, Wt, bo);
   UP(upload(m, Wt, &m->Wt_l2));
+  UP(upload_planes(m, Wt, H, H, &m->Wp_l2));
   UP(upload(m, bo, &m->b_l2));
   UP(upload_raw(m, w->head_w3, (size_t)cfg->num_class * H, &m->W3));
   UP(upload_raw(m, w->head_b3, cfg->num_class, &m->b3));
@@ -551,6 +602,13 @@ extern "C" int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t
   DC_HIP_CHECK(hipMemcpy2DAsync(d_out, (size_t)seq_len * sizeof(float), m->layers[layer].kf,
                                 (size_t)m->kf_taps * sizeof(float), (size_t)seq_len * sizeof(float), m->cfg.d_model,
                                 hipMemcpyDeviceToDevice, st));
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_gemm_mode(dc_model* m, int32_t mode) {
+  DC_REQUIRE(m, "null pointer");
+  DC_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+  m->gemm_mode = mode;
   return DC_OK;
 }
 

@@ -24,7 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // =====================================================================================
 constexpr int G_BN = 128;  // output channels per block
 constexpr int G_BT = 128;  // tokens per block
-constexpr int G_BK = 32;
+#ifndef DC_G_BK
+#define DC_G_BK 32
+#endif
+constexpr int G_BK = DC_G_BK;
+constexpr int G_RPW = G_BK / 4;  // tile rows staged by each of the 4 waves
+#ifndef DC_G_OCC
+#define DC_G_OCC 2
+#endif
 
 __device__ __forceinline__ float gelu_tanh(float x) {
   // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -53,8 +60,56 @@ __device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base) {
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
 
+// Epilogue shared by the fp32 and the bf16x6 GEMM kernels: C[n][t], n = accumulator row, t = lane
+// column.  Accumulator register e of lane half h is row (e&3) + 8 (e>>2) + 4h of its 32x32 tile: the
+// bias of 4 consecutive registers is one float4, and all residual loads of a tile are issued before
+// the first use.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int n_blk, int64_t t_blk, int wn,
+                                              int wt, int i, int h) {
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
+  const int n0 = n_blk + wn * 64 + 4 * h;
+  float4 bv[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) bv[mi][q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+      const int64_t base = (int64_t)(n0 + mi * 32) * g.Tp + t;
+      float* cp = g.C + base;
+      float rv[16];
+      if (RES) {
+        const float* rp = g.R + base;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) rv[e] = rp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp];
+      }
+      float qv = 0.f;
+      if (EPI == EPI_BIAS_RELU_Q) qv = g.q[t];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float4 b4 = bv[mi][e >> 2];
+        const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
+        float v = acc[mi][ni][e] + bias;
+        if (EPI == EPI_BIAS_RES) v += rv[e];
+        if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
+        if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
+        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + rv[e], 0.f);     // head.py:98
+#ifdef DC_ABL_NOEPI
+        asm volatile("" ::"v"(v));
+#else
+        cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
+#endif
+      }
+    }
+  }
+}
+
 template <int EPI, bool LN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, DC_G_OCC) void gemm_kernel(GemmArgs g) {
   // one LDS object (a second __shared__ array next to an LDS-DMA target can make hipcc drain vmcnt early)
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * G_BK * G_BN];
   float(*sA)[G_BK][G_BN] = reinterpret_cast<float(*)[G_BK][G_BN]>(smem);
@@ -80,17 +135,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int wn = wave >> 1, wt = wave & 1;
   const int i = lane & 31, h = lane >> 5;
 
-  // staging: a 32 x 128 fp32 tile = 16 wave-instructions of 1 KiB (2 rows each); wave w moves rows
-  // [8w, 8w+8) of both operands with 4 + 4 LDS-DMA loads per k-tile, no staging registers.
-  const float* gA = g.Wt + (int64_t)(8 * wave + h) * g.N + n_blk + 4 * i;
-  const float* gB = g.X + (int64_t)(8 * wave + h) * g.Tp + t_blk + 4 * i;
-  const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds_addr(&sA[0][8 * wave][0]));
-  const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds_addr(&sB[0][8 * wave][0]));
+  // staging: a G_BK x 128 fp32 tile = G_BK/2 wave-instructions of 1 KiB (2 rows each); wave w moves
+  // rows [G_RPW w, G_RPW (w+1)) of both operands by LDS-DMA, no staging registers.
+  const float* gA = g.Wt + (int64_t)(G_RPW * wave + h) * g.N + n_blk + 4 * i;
+  const float* gB = g.X + (int64_t)(G_RPW * wave + h) * g.Tp + t_blk + 4 * i;
+  const uint32_t ldsA = __builtin_amdgcn_readfirstlane(lds_addr(&sA[0][G_RPW * wave][0]));
+  const uint32_t ldsB = __builtin_amdgcn_readfirstlane(lds_addr(&sB[0][G_RPW * wave][0]));
   auto stage = [&](int buf, int kt) {
     const float* pa = gA + (int64_t)kt * G_BK * g.N;
     const float* pb = gB + (int64_t)kt * G_BK * g.Tp;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < G_RPW / 2; ++j) {
       glds16(pa + (int64_t)(2 * j) * g.N, ldsA + (uint32_t)((buf * G_BK + 2 * j) * G_BN * 4));
       glds16(pb + (int64_t)(2 * j) * g.Tp, ldsB + (uint32_t)((buf * G_BK + 2 * j) * G_BT * 4));
     }
@@ -123,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   const int nk = g.K / G_BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+#ifndef DC_ABL_NOLOAD
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);  // lands in the other buffer while this one is consumed
+#endif
 
     const float* pA = &sA[cur][h][wn * 64 + i];
     const float* pB = &sB[cur][h][wt * 64 + i];
@@ -160,50 +217,172 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C[n][t], n = accumulator row, t = lane column.  Accumulator register e of lane half h
-  // is row (e&3) + 8 (e>>2) + 4h of its 32x32 tile: the bias of 4 consecutive registers is one float4,
-  // and all residual loads of a tile are issued before the first use.
-  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
-  const int n0 = n_blk + wn * 64 + 4 * h;
-  float4 bv[2][4];
+  gemm_epilogue<EPI>(g, acc, n_blk, t_blk, wn, wt, i, h);
+}
+
+// =====================================================================================
+// GEMM on bf16 MFMA with an error-free 3-way split ("bf16x6"): fp32-equivalent accuracy at
+// 6/16 of the fp32-MFMA cost.
+//   x = h + m + l exactly, with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)  (3 x 8 = 24
+//   significant bits).  a*b = sum_{p,q} a_p b_q; the six terms with p + q <= 2 are kept, the dropped
+//   ones are <= 2^-24 |a b| each -- the size of one fp32 rounding.  Products of bf16 pairs are exact
+//   in the fp32 accumulator, so the result differs from an fp32 FMA chain only by accumulation
+//   order.  A (weights) is split once at load time into three planes stored [K/8][N][8] (one
+//   16-byte LDS read per fragment); B (activations, fp32 in HBM) is split on the fly after the
+//   LayerNorm FMA, ~4.5 VALU per element, hidden behind the 24 MFMAs of a k-step.
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef DC_H_BK
+#define DC_H_BK 32
+#endif
+#ifndef DC_H_OCC
+#define DC_H_OCC 2
+#endif
+constexpr int H_BK = DC_H_BK;      // k-tile depth
+constexpr int H_OPT = H_BK / 8;    // k-octets per tile
+constexpr int H_A_BYTES = 3 * H_BK * G_BN * 2;
+constexpr int H_B_BYTES = H_BK * G_BT * 4;
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& mm, bf16x8& ll) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 v = {x[j], x[j + 1]};
+    const bf16x2 hp = __builtin_convertvector(v, bf16x2);
+    const f32x2 r = v - __builtin_convertvector(hp, f32x2);
+    const bf16x2 mp = __builtin_convertvector(r, bf16x2);
+    const f32x2 q = r - __builtin_convertvector(mp, f32x2);
+    const bf16x2 lp = __builtin_convertvector(q, bf16x2);
+    hh[j] = hp[0]; hh[j + 1] = hp[1];
+    mm[j] = mp[0]; mm[j + 1] = mp[1];
+    ll[j] = lp[0]; ll[j + 1] = lp[1];
+  }
+}
+
+template <int EPI, bool LN>
+__global__ __launch_bounds__(256, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * (H_A_BYTES + H_B_BYTES)];
+
+  const unsigned nwg = gridDim.x;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n_blocks = g.N / G_BN;
+  const int nb = bid % n_blocks;
+  const int64_t tb = bid / n_blocks;
+  const int n_blk = nb * G_BN;
+  const int64_t t_blk = tb * G_BT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wt = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+
+  // LDS image per buffer: A planes [3][H_OPT][128 n][8 bf16] then B [H_BK][128 t] fp32
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
+  constexpr int BUF = H_A_BYTES + H_B_BYTES;
+  // A: 3 * H_OPT chunks of 2 KiB (128 n x 16 B); one LDS-DMA instruction moves half a chunk.
+  constexpr int A_INSTR = 3 * H_OPT * 2, A_PER_WAVE = A_INSTR / 4;
+  constexpr int B_PER_WAVE = H_BK / 8;  // 2 rows per instruction, H_BK/4 rows per wave
+  const int K8 = g.K >> 3;
+  auto stage = [&](int buf, int kt) {
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) bv[mi][q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      const int qi = wave * A_PER_WAVE + j;           // wave-uniform
+      const int pl = qi / (2 * H_OPT), o = (qi >> 1) % H_OPT, half = qi & 1;
+      const unsigned short* src =
+          g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + half * 64 + lane) << 3);
+      glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * 128 + half * 64) * 16);
+    }
+    const float* pb = g.X + ((int64_t)kt * H_BK + (H_BK / 4) * wave + h) * g.Tp + t_blk + 4 * i;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+    for (int j = 0; j < B_PER_WAVE; ++j)
+      glds16(pb + (int64_t)(2 * j) * g.Tp, lds0 + buf * BUF + H_A_BYTES + (((H_BK / 4) * wave + 2 * j) * G_BT) * 4);
+  };
+
+  stage(0, 0);
+
+  float rs[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f};
+  if (LN) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int64_t t = t_blk + wt * 64 + ni * 32 + i;
-      const int64_t base = (int64_t)(n0 + mi * 32) * g.Tp + t;
-      float* cp = g.C + base;
-      float rv[16];
-      if (RES) {
-        const float* rp = g.R + base;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) rv[e] = rp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp];
-      }
-      float qv = 0.f;
-      if (EPI == EPI_BIAS_RELU_Q) qv = g.q[t];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float4 b4 = bv[mi][e >> 2];
-        const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
-        float v = acc[mi][ni][e] + bias;
-        if (EPI == EPI_BIAS_RES) v += rv[e];
-        if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
-        if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
-        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + rv[e], 0.f);     // head.py:98
-        cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
-      }
+      const float m = g.mean[t], r = g.rstd[t];
+      rs[ni] = r;
+      nm[ni] = -m * r;
     }
   }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nk = g.K / H_BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+
+    const unsigned char* bufp = smem6 + cur * BUF;
+    const bf16x8* pA = reinterpret_cast<const bf16x8*>(bufp);
+    const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
+#pragma unroll
+    for (int s = 0; s < H_BK / 16; ++s) {
+      bf16x8 af[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[pl][mi] = pA[(pl * H_OPT + 2 * s + h) * 128 + wn * 64 + mi * 32 + i];
+      bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = pB[(16 * s + 8 * h + j) * G_BT + wt * 64 + ni * 32 + i];
+          x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
+        }
+        split3(x, bh[ni], bm[ni], bl[ni]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          f32x16 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][mi], bh[ni], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bm[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bl[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bh[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bm[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bh[ni], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<EPI>(g, acc, n_blk, t_blk, wn, wt, i, h);
 }
 
 template <int EPI, bool LN>
 static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
   const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
-  hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
+  if (g.Wp) {
+    DC_REQUIRE(g.K % H_BK == 0, "K not a multiple of the bf16x6 k-tile");
+    hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
+  } else
+    hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -279,6 +279,10 @@ class HipModel:
     def device_bytes(self) -> int:
         return int(_lib.lib().dc_model_device_bytes(self._h))
 
+    def set_gemm_mode(self, mode: str):
+        """"f32": fp32-input MFMA; "bf16x6": error-free 3-way bf16 split on bf16 MFMA (fp32-equivalent)."""
+        _lib.check(_lib.lib().dc_model_set_gemm_mode(self._h, {"f32": 0, "bf16x6": 1}[mode]))
+
     def set_profiling(self, on: bool):
         _lib.check(_lib.lib().dc_model_set_profiling(self._h, int(on)))
 

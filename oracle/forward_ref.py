@@ -141,12 +141,13 @@ def head_forward(sd: dict, x: torch.Tensor, input_quals: torch.Tensor) -> torch.
 
 
 @torch.no_grad()
-def forward(sd: dict, input_ids, input_quals, cfg: HyenaDNAConfig | None = None) -> torch.Tensor:
-    """logits f32[B, L, 2] = head(backbone(input_ids), input_quals)."""
+def forward(sd: dict, input_ids, input_quals, cfg: HyenaDNAConfig | None = None, dtype=torch.float32) -> torch.Tensor:
+    """logits [B, L, 2] = head(backbone(input_ids), input_quals).  dtype=float32 is the reference's
+    arithmetic; float64 gives an error yardstick for the GPU paths."""
     cfg = cfg or HyenaDNAConfig()
     ids = torch.as_tensor(input_ids, dtype=torch.long)
-    q = torch.as_tensor(input_quals, dtype=torch.float32)
-    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    q = torch.as_tensor(input_quals, dtype=torch.float32).to(dtype)
+    sd = {k: torch.as_tensor(v).to(dtype) for k, v in sd.items()}
     hidden = backbone_forward(sd, ids, cfg)
     return head_forward(sd, hidden, q)
 

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ATOL = 2e-4
 
 
-@pytest.fixture(scope="module")
-def env(hip_lib):
+@pytest.fixture(scope="module", params=["f32", "bf16x6"])
+def env(hip_lib, request):
     import torch
 
     from deepchopper_amd import _lib, ops
@@ -23,6 +23,7 @@ def env(hip_lib):
     assert _lib.device_count() >= 1, "GPU tests need a HIP device; there is no CPU fallback"
     sd = synthetic_state_dict(0)
     model = ops.HipModel(sd, HyenaDNAConfig())
+    model.set_gemm_mode(request.param)
     return torch, ops, sd, model
 
 
@@ -156,3 +157,29 @@ def test_forward_at_bench_shape_properties(env):
     for b in (0, 100, 255):
         ref = fr.forward(sd, ids[b: b + 1], q[b: b + 1]).numpy()[0]
         _check(out[b], ref)
+
+
+def test_gemm_modes_error_vs_float64(hip_lib):
+    """The bf16x6 GEMM path (error-free 3-way bf16 split) is fp32-equivalent: against a float64
+    evaluation of the oracle its error is of the same size as the fp32-MFMA path's and the torch-fp32
+    oracle's own."""
+    import torch
+
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = synthetic_state_dict(3)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    rng = np.random.default_rng(77)
+    ids, q = _inputs(rng, 4, 700)
+    ref64 = fr.forward(sd, ids, q, dtype=torch.float64).numpy()
+    ref32 = fr.forward(sd, ids, q).numpy()
+    errs = {"oracle_f32": np.abs(ref32 - ref64).max()}
+    for mode in ("f32", "bf16x6"):
+        model.set_gemm_mode(mode)
+        out = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
+        errs[mode] = np.abs(out - ref64).max()
+    print("max |logit - float64 oracle|:", {k: float(v) for k, v in errs.items()})
+    assert errs["f32"] < 1e-4 and errs["bf16x6"] < 1e-4
+    assert errs["bf16x6"] < 4 * max(errs["f32"], errs["oracle_f32"]) + 1e-6
