@@ -44,7 +44,7 @@ struct dc_model {
   std::vector<LayerDev> layers;
   float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
   unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
-  int gemm_mode = 0;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split on bf16 MFMA)
+  int gemm_mode = 1;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split on bf16 MFMA, fp32-equivalent)
   int64_t kf_taps = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
@@ -303,7 +303,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     maxP = std::max(maxP, nblk[r]);
     minP = std::min(minP, nblk[r]);
   }
-  const int64_t Tp = ((blocks * 32 + 127) / 128) * 128;
+  const int64_t Tp = ((blocks * 32 + 255) / 256) * 256;  // multiple of every GEMM token tile
   DC_REQUIRE(Tp < ((int64_t)1 << 31), "batch too large (token count must fit int32)");
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
   const int64_t n_tb = Tp / 32;
@@ -483,7 +483,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   }
   dc_model* m = new dc_model();
   m->cfg = *cfg;
-  if (const char* e = getenv("DC_GEMM_MODE")) m->gemm_mode = (strcmp(e, "bf16x6") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+  if (const char* e = getenv("DC_GEMM_MODE")) m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : 1;
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
   const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;

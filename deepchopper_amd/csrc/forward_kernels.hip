@@ -64,21 +64,20 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(
 // column.  Accumulator register e of lane half h is row (e&3) + 8 (e>>2) + 4h of its 32x32 tile: the
 // bias of 4 consecutive registers is one float4, and all residual loads of a tile are issued before
 // the first use.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], int n_blk, int64_t t_blk, int wn,
-                                              int wt, int i, int h) {
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NI], int n_w0, int64_t t_w0, int i,
+                                              int h) {
+  // n_w0 / t_w0: first output channel / token of this wave's (32 MI) x (32 NI) sub-tile
   constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
-  const int n0 = n_blk + wn * 64 + 4 * h;
-  float4 bv[2][4];
+  const int n0 = n_w0 + 4 * h;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi) {
+    float4 bv[4];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) bv[mi][q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
+    for (int q4 = 0; q4 < 4; ++q4) bv[q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int64_t t = t_w0 + ni * 32 + i;
       const int64_t base = (int64_t)(n0 + mi * 32) * g.Tp + t;
       float* cp = g.C + base;
       float rv[16];
@@ -91,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
       if (EPI == EPI_BIAS_RELU_Q) qv = g.q[t];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float4 b4 = bv[mi][e >> 2];
+        const float4 b4 = bv[e >> 2];
         const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
         float v = acc[mi][ni][e] + bias;
         if (EPI == EPI_BIAS_RES) v += rv[e];
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(256, DC_G_OCC) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue<EPI>(g, acc, n_blk, t_blk, wn, wt, i, h);
+  gemm_epilogue<EPI, 2, 2>(g, acc, n_blk + wn * 64, t_blk + wt * 64, i, h);
 }
 
 // =====================================================================================
@@ -236,7 +235,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef DC_H_BK
-#define DC_H_BK 32
+#define DC_H_BK 16
 #endif
 #ifndef DC_H_OCC
 #define DC_H_OCC 2
@@ -244,7 +243,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int H_BK = DC_H_BK;      // k-tile depth
 constexpr int H_OPT = H_BK / 8;    // k-octets per tile
 constexpr int H_A_BYTES = 3 * H_BK * G_BN * 2;
-constexpr int H_B_BYTES = H_BK * G_BT * 4;
 
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& mm, bf16x8& ll) {
 #pragma unroll
@@ -261,9 +259,84 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
   }
 }
 
+#ifndef DC_H_STAGES
+#define DC_H_STAGES 2
+#endif
+#ifndef DC_H_BT
+#define DC_H_BT 256   // tokens per block
+#endif
+#ifndef DC_H_NW
+#define DC_H_NW 8     // waves per block; every wave owns all 128 output channels x 32 tokens
+#endif
+constexpr int H_BT = DC_H_BT, H_NW = DC_H_NW;
+constexpr int H_MI = G_BN / 32;            // 4 accumulator tiles down the channel axis
+constexpr int H_NI = H_BT / (32 * H_NW);   // tiles along the token axis per wave
+constexpr int H_B_BYTES = H_BK * H_BT * 4;
+static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered by the waves");
+
+// Epilogue through LDS: the MFMA accumulator has the token on the lane and the channel on the
+// register (one 4-byte store per lane and register = 64 narrow store instructions per wave and
+// tile).  Each wave bounces its 32x32 tiles through a private 4 KiB LDS patch and reads them back
+// row-wise, so residual loads and result stores are 16 B per lane and every wave instruction moves
+// eight full 128-byte lines.
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][NI], float* patch, int n_w0,
+                                                  int64_t t_w0, int lane) {
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
+  const int i = lane & 31, h = lane >> 5;
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;  // read-back: row rr (+8 per pass), 4 tokens at column c4
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int64_t t = t_w0 + ni * 32 + c4;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_BIAS_RELU_Q) qv = *reinterpret_cast<const float4*>(g.q + t);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[mi][ni][e];
+      // same wave writes and reads the patch: LDS operations of one wave complete in order
+      float4 v[4], rv[4];
+      float bias[4];
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) {
+        const int n = n_w0 + mi * 32 + p4 * 8 + rr;
+        bias[p4] = g.bias[n];
+        if (RES) rv[p4] = *reinterpret_cast<const float4*>(g.R + (int64_t)n * g.Tp + t);
+      }
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) v[p4] = *reinterpret_cast<const float4*>(patch + (p4 * 8 + rr) * 32 + c4);
+#pragma unroll
+      for (int p4 = 0; p4 < 4; ++p4) {
+        const int n = n_w0 + mi * 32 + p4 * 8 + rr;
+        float o[4] = {v[p4].x + bias[p4], v[p4].y + bias[p4], v[p4].z + bias[p4], v[p4].w + bias[p4]};
+        const float r4[4] = {RES ? rv[p4].x : 0.f, RES ? rv[p4].y : 0.f, RES ? rv[p4].z : 0.f, RES ? rv[p4].w : 0.f};
+        const float q4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float x = o[c];
+          if (EPI == EPI_BIAS_RES) x += r4[c];
+          if (EPI == EPI_BIAS_GELU) x = g.gelu_tanh ? gelu_tanh(x) : gelu_erf(x);
+          if (EPI == EPI_BIAS_RELU_Q) x = fmaxf(x, 0.f) + q4[c];       // head.py:94,97
+          if (EPI == EPI_BIAS_RES_RELU) x = fmaxf(x + r4[c], 0.f);      // head.py:98
+          o[c] = x;
+        }
+#ifdef DC_ABL_NOEPI
+        asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+#else
+        *reinterpret_cast<float4*>(g.C + (int64_t)n * g.Tp + t) = make_float4(o[0], o[1], o[2], o[3]);
+#endif
+      }
+    }
+  }
+}
+
 template <int EPI, bool LN>
-__global__ __launch_bounds__(256, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * (H_A_BYTES + H_B_BYTES)];
+__global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
+  constexpr int BUF = H_A_BYTES + H_B_BYTES;
+  constexpr int EPI_BYTES = H_NW * 32 * 32 * 4;
+  constexpr int S = DC_H_STAGES;  // LDS ring depth: tiles kt+1 .. kt+S-1 are in flight while tile kt is consumed
+  constexpr int SMEM = (S * BUF > EPI_BYTES) ? S * BUF : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem6[SMEM];
 
   const unsigned nwg = gridDim.x;
   unsigned bid = blockIdx.x;
@@ -275,112 +348,138 @@ __global__ __launch_bounds__(256, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
   const int nb = bid % n_blocks;
   const int64_t tb = bid / n_blocks;
   const int n_blk = nb * G_BN;
-  const int64_t t_blk = tb * G_BT;
+  const int64_t t_blk = tb * H_BT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wt = wave & 1;
+  const int t_w = wave * (32 * H_NI);  // wave origin inside the block tile (all 128 channels)
   const int i = lane & 31, h = lane >> 5;
 
-  // LDS image per buffer: A planes [3][H_OPT][128 n][8 bf16] then B [H_BK][128 t] fp32
+  // LDS image per buffer: A planes [3][H_OPT][128 n][8 bf16] then B [H_BK][H_BT] fp32
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
-  constexpr int BUF = H_A_BYTES + H_B_BYTES;
-  // A: 3 * H_OPT chunks of 2 KiB (128 n x 16 B); one LDS-DMA instruction moves half a chunk.
-  constexpr int A_INSTR = 3 * H_OPT * 2, A_PER_WAVE = A_INSTR / 4;
-  constexpr int B_PER_WAVE = H_BK / 8;  // 2 rows per instruction, H_BK/4 rows per wave
+  // one LDS-DMA instruction moves 1 KiB: half a 128-channel A chunk, or 256 floats of the B tile
+  constexpr int A_INSTR = 3 * H_OPT * 2;
+  constexpr int B_INSTR = H_B_BYTES / 1024;
+  // LDS-DMA instructions per wave and k-tile, rounded DOWN: waves that issue one more only wait a little
+  // longer than needed (waiting for fewer outstanding operations is always safe)
+  constexpr int PW = (A_INSTR + B_INSTR) / H_NW;
   const int K8 = g.K >> 3;
+  // per-lane position inside one B instruction (256 consecutive floats of the row-major [k][H_BT] tile)
+  const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
+  constexpr int B_ROWS_PER_INSTR = 256 / H_BT > 0 ? 256 / H_BT : 1;
   auto stage = [&](int buf, int kt) {
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-      const int qi = wave * A_PER_WAVE + j;           // wave-uniform
-      const int pl = qi / (2 * H_OPT), o = (qi >> 1) % H_OPT, half = qi & 1;
-      const unsigned short* src =
-          g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + half * 64 + lane) << 3);
-      glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * 128 + half * 64) * 16);
+    for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
+      if (q < A_INSTR) {
+        const int pl = q / (2 * H_OPT), o = (q >> 1) % H_OPT, half = q & 1;
+        const unsigned short* src =
+            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + half * 64 + lane) << 3);
+        glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * 128 + half * 64) * 16);
+      } else {
+        const int bq = q - A_INSTR;
+        const int row = (H_BT >= 256) ? (bq * 256) / H_BT : bq * B_ROWS_PER_INSTR + b_row_l;
+        const int col = (H_BT >= 256) ? (bq * 256) % H_BT + lane * 4 : b_col_l;
+        const float* src = g.X + ((int64_t)kt * H_BK + row) * g.Tp + t_blk + col;
+        glds16(src, lds0 + buf * BUF + H_A_BYTES + bq * 1024);
+      }
     }
-    const float* pb = g.X + ((int64_t)kt * H_BK + (H_BK / 4) * wave + h) * g.Tp + t_blk + 4 * i;
-#pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j)
-      glds16(pb + (int64_t)(2 * j) * g.Tp, lds0 + buf * BUF + H_A_BYTES + (((H_BK / 4) * wave + 2 * j) * G_BT) * 4);
   };
 
-  stage(0, 0);
-
-  float rs[2] = {1.f, 1.f}, nm[2] = {0.f, 0.f};
-  if (LN) {
+  const int nk = g.K / H_BK;  // >= 16 for every GEMM of this model, so the ring always fills
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t t = t_blk + wt * 64 + ni * 32 + i;
+  for (int st = 0; st < S - 1; ++st) stage(st, st);
+
+  float rs[H_NI], nm[H_NI];
+#pragma unroll
+  for (int ni = 0; ni < H_NI; ++ni) {
+    rs[ni] = 1.f;
+    nm[ni] = 0.f;
+    if (LN) {
+      const int64_t t = t_blk + t_w + ni * 32 + i;
       const float m = g.mean[t], r = g.rstd[t];
       rs[ni] = r;
       nm[ni] = -m * r;
     }
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[H_MI][H_NI];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < H_MI; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < H_NI; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // tile 0 has landed when at most the S-2 younger tiles are outstanding (vmcnt counts in issue order)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
   __syncthreads();
 
-  const int nk = g.K / H_BK;
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-
+#ifndef DC_ABL_NOLOAD
+    if (kt + S - 1 < nk) {
+      int nxt = cur + S - 1;
+      if (nxt >= S) nxt -= S;
+      stage(nxt, kt + S - 1);  // overwrites the buffer consumed in iteration kt-1 (all waves passed its barrier)
+    }
+#endif
     const unsigned char* bufp = smem6 + cur * BUF;
     const bf16x8* pA = reinterpret_cast<const bf16x8*>(bufp);
     const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
 #pragma unroll
     for (int s = 0; s < H_BK / 16; ++s) {
-      bf16x8 af[3][2];
+      bf16x8 bh[H_NI], bm[H_NI], bl[H_NI];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[pl][mi] = pA[(pl * H_OPT + 2 * s + h) * 128 + wn * 64 + mi * 32 + i];
-      bf16x8 bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < H_NI; ++ni) {
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float v = pB[(16 * s + 8 * h + j) * G_BT + wt * 64 + ni * 32 + i];
+          const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
           x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
         }
         split3(x, bh[ni], bm[ni], bl[ni]);
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < H_MI; ++mi) {
+        bf16x8 af[3];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * 128 + mi * 32 + i];
+#pragma unroll
+        for (int ni = 0; ni < H_NI; ++ni) {
           f32x16 c = acc[mi][ni];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][mi], bh[ni], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bm[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bl[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mi], bh[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bm[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mi], bh[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bh[ni], c, 0, 0, 0);  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bm[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bl[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bh[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bm[ni], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bh[ni], c, 0, 0, 0);
           acc[mi][ni] = c;
         }
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // next iteration reads tile kt+1: it has landed when only the tiles younger than it are outstanding
+    if (kt + S - 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring draining: at most S-2 short iterations
+    }
     __syncthreads();
+    cur = cur + 1 == S ? 0 : cur + 1;
   }
-  gemm_epilogue<EPI>(g, acc, n_blk, t_blk, wn, wt, i, h);
+#ifdef DC_H_DIRECT_EPI
+  gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
+#else
+  gemm_epilogue_lds<EPI, H_MI, H_NI>(g, acc, reinterpret_cast<float*>(smem6) + wave * 1024, n_blk, t_blk + t_w, lane);
+#endif
 }
 
 template <int EPI, bool LN>
 static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
   const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
   if (g.Wp) {
-    DC_REQUIRE(g.K % H_BK == 0, "K not a multiple of the bf16x6 k-tile");
-    hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
+    DC_REQUIRE(g.K % H_BK == 0 && g.Tp % H_BT == 0, "shape not aligned to the bf16x6 tile");
+    const unsigned grid6 = (unsigned)((g.N / G_BN) * (g.Tp / H_BT));
+    hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
   } else
     hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
   DC_LAUNCH_CHECK();
@@ -626,9 +725,15 @@ __global__ __launch_bounds__(256) void hyena_kernel(HyenaArgs a) {
           const int pp = p0 + jj;
           if (pp >= p && pp < P) {  // wave-uniform
             const int base = 32 + 32 * (pp - p) + n - 16 * h;
+            float af[16];  // all 16 taps of this Toeplitz block are requested before the first MFMA
+#pragma unroll
+            for (int s = 0; s < 16; ++s) af[s] = kp[base - s];
+#ifdef DC_HY_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-              acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[base - s], zf[s], acc[jj], 0, 0, 0);
+              acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], zf[s], acc[jj], 0, 0, 0);
           }
         }
       }

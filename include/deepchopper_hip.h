@@ -241,7 +241,7 @@ int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t seq_len, f
  * chain).  1 = "bf16x6": every fp32 operand is split error-free into three bf16 terms
  * (x = h + m + l, 24 significant bits) and the six leading cross products run on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-equivalent accuracy (dropped terms
- * <= 2^-24 relative) at 6/16 of the fp32-MFMA cost.  Default: $DC_GEMM_MODE ("f32" | "bf16x6"), else 0. */
+ * <= 2^-24 relative) at 6/16 of the fp32-MFMA cost.  Default: 1; $DC_GEMM_MODE = "f32" selects 0. */
 int dc_model_set_gemm_mode(dc_model* m, int32_t mode);
 
 /* Per-stage device timing with HIP events recorded on the stream the kernels are launched on.

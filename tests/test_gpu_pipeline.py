@@ -1,0 +1,132 @@
+"""GPU end-to-end tests: FASTQ -> tokenise -> forward -> smooth/intervals through the product API,
+the reference's `.pt` wire format, and the `predict` command line."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(hip_lib):
+    import torch
+
+    from deepchopper_amd import _lib
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+    from deepchopper_amd.weights import synthetic_state_dict
+
+    assert _lib.device_count() >= 1
+    sd = synthetic_state_dict(0)
+    pipe = PredictPipeline(DeepChopper.from_state_dict(sd))
+    return torch, sd, pipe
+
+
+def _oracle_reads(sd, ids, seqs, quals, batch=None):
+    """Oracle predict: `batch=None` -> every read alone (zero padding); else reference batches."""
+    from oracle import dc_oracle as o
+    from oracle import forward_ref as fr
+
+    feats = []
+    for i, s, q in zip(ids, seqs, quals):
+        rec = o.parse_fastq_record(i, s.decode(), q.decode())
+        feats.append(o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"]))
+    out = {}
+    step = batch or 1
+    for b0 in range(0, len(feats), step):
+        bt = o.collate(feats[b0: b0 + step])
+        logits = fr.forward(sd, bt["input_ids"], bt["input_quals"]).numpy()
+        for rid, p in o.load_predicts_from_batch({"prediction": logits, "target": bt["labels"], "seq": bt["input_ids"],
+                                                  "id": bt["id"]}).items():
+            out[rid] = (p, logits)
+    return out
+
+
+def _margin_ok(pred, ref_pred):
+    # labels may only differ where the oracle's own logit margin is within the fp32 noise floor
+    return np.mean(pred != ref_pred) < 2e-3
+
+
+def test_mixed_length_native_equals_per_read_oracle(env):
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+
+    seqs, quals, ids = synth.synth_reads_mixed(24, 100, 1500, seed=42)
+    out, res = pipe.predict_reads(ids, seqs, quals)
+    ref = _oracle_reads(sd, ids, seqs, quals)
+    for r in out:
+        p, _ = ref[r["id"]]
+        assert len(r["prediction"]) == len(p.prediction)
+        assert _margin_ok(r["prediction"], p.prediction)
+        if np.array_equal(r["prediction"], p.prediction):
+            assert np.array_equal(r["smooth"], p.smooth_label(21))
+            assert r["intervals"] == p.smooth_and_select_intervals(21, 13, 20)
+
+
+def test_reference_padding_equals_batched_oracle(env):
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+
+    seqs, quals, ids = synth.synth_reads_mixed(12, 150, 700, seed=7)
+    out, res = pipe.predict_reads(ids, seqs, quals, reference_padding=True)
+    ref = _oracle_reads(sd, ids, seqs, quals, batch=12)
+    got = res["logits"].cpu().numpy()
+    _, ref_logits = ref[ids[0]]
+    assert np.abs(got - ref_logits).max() < 2e-4
+    for r in out:
+        p, _ = ref[r["id"]]
+        assert _margin_ok(r["prediction"], p.prediction)
+
+
+def test_pt_wire_format_roundtrip(env, tmp_path):
+    torch, sd, pipe = env
+    from deepchopper_amd import rs_api, synth
+    from deepchopper_amd.predict import write_pt_batch
+    from oracle import dc_oracle as o
+
+    seq, qual, ids = synth.synth_reads_fixed(12, 400, seed=42)
+    seqs, quals = [s.tobytes() for s in seq], [q.tobytes() for q in qual]
+    out, res = pipe.predict_reads(ids, seqs, quals, reference_padding=True)
+    path = str(tmp_path / "0" / "0_0.pt")
+    write_pt_batch(path, res, ids)
+    d = torch.load(path, weights_only=True)
+    assert d["prediction"].dtype == torch.float32 and d["prediction"].shape == (12, 401, 2)
+    assert d["target"].dtype == torch.int64 and d["seq"].dtype == torch.int64 and d["id"].shape == (12, 256)
+    assert d["qual"].dtype == torch.float32 and d["id"].dtype == torch.int64
+    mine = rs_api.load_predicts_from_batch_pt(path)                         # GPU argmax + mask
+    theirs = o.load_predicts_from_batch({k: v.numpy() for k, v in d.items()})  # oracle of the Rust loader
+    assert set(mine) == set(theirs) == set(ids)
+    for r in out:
+        assert mine[r["id"]].prediction == theirs[r["id"]].prediction.tolist() == r["prediction"].tolist()
+        assert mine[r["id"]].seq == theirs[r["id"]].seq == seqs[ids.index(r["id"])].decode()
+        assert mine[r["id"]].smooth_and_select_intervals(21, 13, 20) == r["intervals"]
+
+
+def test_cli_predict(env, tmp_path):
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+    from deepchopper_amd.weights import save_state_dict
+
+    ckpt = tmp_path / "ckpt" / "model.safetensors"
+    save_state_dict(sd, str(ckpt))
+    seq, qual, ids = synth.synth_reads_fixed(30, 300, seed=42)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seq, qual, ids))
+    out = tmp_path / "predictions"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "deepchopper_amd.cli", "predict", str(fq), "-g", "1", "-o", str(out), "-b", "12",
+           "-m", str(ckpt.parent), "--native"]
+    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    files = sorted(os.listdir(out / "0"))
+    assert files == ["0.intervals.tsv", "0_0.pt", "0_1.pt", "0_2.pt"]
+    lines = (out / "0" / "0.intervals.tsv").read_text().strip().split("\n")
+    assert [l.split("\t")[0] for l in lines] == ids
+    d = torch.load(out / "0" / "0_2.pt", weights_only=True)
+    assert d["prediction"].shape[0] == 6
+    # no-GPU flag is rejected loudly
+    proc = subprocess.run(cmd[:5] + ["-g", "0"], cwd=root, capture_output=True, text=True, timeout=120)
+    assert proc.returncode != 0 and "no CPU fallback" in proc.stderr
