@@ -58,6 +58,7 @@ struct HyenaArgs {
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
+int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);

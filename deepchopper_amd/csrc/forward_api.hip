@@ -433,7 +433,9 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.D = D;
       a.CH = CH;
       ProfScope ps(m, st, "hyena");
-      if ((rc = launch_hyena(st, a, m->n_groups, m->max_P))) return rc;
+      static const bool old_hyena = getenv("DC_HYENA_V1") != nullptr;  // A/B switch, default = hyena2
+      if ((rc = old_hyena ? launch_hyena(st, a, m->n_groups, m->max_P) : launch_hyena2(st, a, m->n_groups, m->max_P)))
+        return rc;
     }
     if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false, EPI_BIAS_RES, D, D)))
       return rc;

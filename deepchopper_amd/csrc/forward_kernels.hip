@@ -766,6 +766,169 @@ __global__ __launch_bounds__(256) void hyena_kernel(HyenaArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------
+// hyena2: same mathematics, loop order swapped so that every u element is fetched once.
+// A workgroup owns (read group g, channel c, output chunk oc of 32 blocks).  It walks the input blocks
+// p = 0 .. last; the 256 threads build z[p] = sf(v) * sf(x1) for the 32 reads cooperatively (one float4
+// per thread) into a double-buffered LDS tile; wave w holds the accumulators of output blocks
+// p' = 32 oc + w, w+4, ... (8 tiles) and adds T_{p'-p} Z[p] for every owned p' >= p.
+// -------------------------------------------------------------------------------------
+constexpr int HY_ZSTRIDE = 36;  // floats per read row of the z tile: 16-B aligned rows, conflict-free b128 reads
+
+__global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
+  extern __shared__ float s_mem[];
+  const int g = blockIdx.x;
+  const int c = blockIdx.y;
+  const int oc = blockIdx.z;
+  const int P = a.grp_P[g];
+  if (32 * oc >= P) return;  // block-uniform: this group has no output blocks in the chunk
+  const int p_out0 = 32 * oc;
+  const int p_last = (p_out0 + 31 < P - 1) ? p_out0 + 31 : P - 1;  // last input (= last output) block
+  const int ktaps = 32 * (p_last + 1);
+  float* s_k = s_mem;                       // [32 zeros | ktaps]
+  float* s_z = s_mem + 32 + 32 * (32 * (oc + 1));  // 2 x [32][HY_ZSTRIDE]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+
+  {
+    const float* krow = a.kf + (int64_t)c * a.kf_stride;
+    for (int j = tid; j < 32 + ktaps; j += 256) s_k[j] = j < 32 ? 0.f : krow[j - 32];
+  }
+
+  // ---- producer role: thread -> (read zr, 4 steps zq4 .. zq4+3) of the z tile ----
+  const int zr = tid >> 3, zq4 = (tid & 7) * 4;
+  int rz = a.grp_reads[g * 32 + zr];
+  const bool z_valid = rz >= 0;
+  if (!z_valid) rz = a.grp_reads[g * 32];
+  const int64_t z_off = a.toff[rz];
+  const int z_nblk = z_valid ? a.nblk[rz] : 0;
+  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + z_off;
+  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + z_off;
+  const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
+              bx1 = a.sb[a.D + c];
+  const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
+              wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
+
+  auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
+    l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < z_nblk) {
+      const int64_t t = 32 * p + zq4;
+      if (t > 0) {
+        l1 = *reinterpret_cast<const float4*>(ux1 + t - 4);
+        lv = *reinterpret_cast<const float4*>(uv + t - 4);
+      }
+      c1 = *reinterpret_cast<const float4*>(ux1 + t);
+      cv = *reinterpret_cast<const float4*>(uv + t);
+    }
+  };
+  auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
+    // conv1d(padding=2)[..., :L]: out[t] = w0 u[t-2] + w1 u[t-1] + w2 u[t] + b ;  z = sf(v) * sf(x1)
+    float4 z;
+    const bool act = p < z_nblk;
+    z.x = fmaf(wx1_0, l1.z, fmaf(wx1_1, l1.w, fmaf(wx1_2, c1.x, bx1))) * fmaf(wv_0, lv.z, fmaf(wv_1, lv.w, fmaf(wv_2, cv.x, bv)));
+    z.y = fmaf(wx1_0, l1.w, fmaf(wx1_1, c1.x, fmaf(wx1_2, c1.y, bx1))) * fmaf(wv_0, lv.w, fmaf(wv_1, cv.x, fmaf(wv_2, cv.y, bv)));
+    z.z = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
+    z.w = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
+    if (!act) z = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(s_z + (p & 1) * (32 * HY_ZSTRIDE) + zr * HY_ZSTRIDE + zq4) = z;
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+  {
+    float4 l1, c1, lv, cv;
+    z_load(0, l1, c1, lv, cv);
+    z_store(0, l1, c1, lv, cv);
+  }
+  __syncthreads();
+
+  for (int p = 0; p <= p_last; ++p) {
+    float4 l1, c1, lv, cv;
+    const bool more = p < p_last;
+    if (more) z_load(p + 1, l1, c1, lv, cv);  // lands behind this block's MFMAs
+
+    // B fragment of input block p: z[n][16h + s]
+    const float* zrow = s_z + (p & 1) * (32 * HY_ZSTRIDE) + n * HY_ZSTRIDE + 16 * h;
+    float zf[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(zrow + 4 * j);
+      zf[4 * j + 0] = v.x;
+      zf[4 * j + 1] = v.y;
+      zf[4 * j + 2] = v.z;
+      zf[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int pp = p_out0 + wave + 4 * m;  // owned output block (wave-uniform)
+      if (pp >= p && pp <= p_last) {
+        const int base = 32 + 32 * (pp - p) + n - 16 * h;
+        float af[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) af[s] = s_k[base - s];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], zf[s], acc[m], 0, 0, 0);
+      }
+    }
+    if (more) z_store(p + 1, l1, c1, lv, cv);
+    __syncthreads();
+  }
+
+  // ---- epilogue: y = conv * sf(x0); lane (n, h) holds q' = (e&3) + 8 (e>>2) + 4 h of its read ----
+  int r = a.grp_reads[g * 32 + n];
+  const bool valid = r >= 0;
+  if (!valid) r = a.grp_reads[g * 32];
+  const int64_t off = a.toff[r];
+  const int my_nblk = valid ? a.nblk[r] : 0;
+  const float* ux0 = a.u + (int64_t)c * a.Tp + off;
+  float* yrow = a.y + (int64_t)c * a.Tp + off;
+  const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int pp = p_out0 + wave + 4 * m;
+    if (pp <= p_last && pp < my_nblk) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int64_t t = 32 * pp + 8 * gq + 4 * h;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t > 0) lo = *reinterpret_cast<const float4*>(ux0 + t - 4);
+        const float4 cu = *reinterpret_cast<const float4*>(ux0 + t);
+        const float g0 = fmaf(wx0_0, lo.z, fmaf(wx0_1, lo.w, fmaf(wx0_2, cu.x, bx0)));
+        const float g1 = fmaf(wx0_0, lo.w, fmaf(wx0_1, cu.x, fmaf(wx0_2, cu.y, bx0)));
+        const float g2 = fmaf(wx0_0, cu.x, fmaf(wx0_1, cu.y, fmaf(wx0_2, cu.z, bx0)));
+        const float g3 = fmaf(wx0_0, cu.y, fmaf(wx0_1, cu.z, fmaf(wx0_2, cu.w, bx0)));
+        float4 o;
+        o.x = acc[m][4 * gq + 0] * g0;
+        o.y = acc[m][4 * gq + 1] * g1;
+        o.z = acc[m][4 * gq + 2] * g2;
+        o.w = acc[m][4 * gq + 3] * g3;
+        *reinterpret_cast<float4*>(yrow + t) = o;
+      }
+    }
+  }
+}
+
+int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
+  const int n_oc = (max_P + 31) / 32;
+  // LDS of the largest chunk: filter taps [32 + 32 * 32 * n_oc] + two z tiles
+  const size_t lds = ((size_t)32 + 32 * 32 * (size_t)n_oc + 2 * 32 * HY_ZSTRIDE) * sizeof(float);
+  DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
+  if (lds > 64 * 1024) {
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena2_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(hyena2_kernel, dim3(n_groups, a.D, n_oc), dim3(256), lds, st, a);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   DC_REQUIRE(a.D % a.CH == 0, "CH must divide D");
   const size_t lds = (size_t)a.CH * (32 + 32 * (size_t)max_P) * sizeof(float);
