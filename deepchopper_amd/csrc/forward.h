@@ -11,6 +11,7 @@ enum GemmEpilogue {
   EPI_BIAS_GELU,      // C = gelu(acc + bias)                             (fc1)
   EPI_BIAS_RELU_Q,    // C = relu(acc + bias) + q[t]                      (head linear1 + quality residual)
   EPI_BIAS_RES_RELU,  // C = relu(acc + bias + R)                         (head linear2 + residual)
+  EPI_HEAD2_FUSED,    // o = relu(acc + bias + R) is not stored: part[nb][t][:] = W3[:, n-block] . o   (linear3 fused)
 };
 
 struct GemmArgs {
@@ -23,6 +24,8 @@ struct GemmArgs {
   const float* q;     // [Tp]    quality or nullptr
   const float* mean;  // [Tp]    LayerNorm statistics of X's tokens (LN variants)
   const float* rstd;  // [Tp]
+  const float* w3;    // [2][N]  head linear3 weight (EPI_HEAD2_FUSED)
+  float* part;        // [N/128][Tp][2] partial logits per 128-channel block (EPI_HEAD2_FUSED)
   int K, N;
   int64_t Tp;
   int gelu_tanh;
@@ -63,6 +66,12 @@ int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* qual
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);
 int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd);
+int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
+                       const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                       float* logits);
+int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
+                    const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
+                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad);
 int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
                     const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                     float* logits);

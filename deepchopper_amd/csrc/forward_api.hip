@@ -1,5 +1,6 @@
 // Model handle, weight repacking and forward orchestration behind the C ABI (F1-F3).
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <numeric>
 #include <vector>
@@ -44,13 +45,14 @@ struct dc_model {
   std::vector<LayerDev> layers;
   float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
   unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
+  float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
   int gemm_mode = 1;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split on bf16 MFMA, fp32-equivalent)
   int64_t kf_taps = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
 
   // workspace (grown on demand)
-  DevBuf x, u, y, hmid, obuf, mean, rstd, qpad, idx;
+  DevBuf x, u, y, hmid, obuf, mean, rstd, qpad, idx, part;
   int64_t Tp_cap = 0;
 
   // index arrays: host mirror of the last geometry + pinned staging
@@ -177,6 +179,7 @@ int ensure_workspace(dc_model* m, int64_t Tp) {
   if ((rc = ensure(m->mean, (size_t)Tp * f))) return rc;
   if ((rc = ensure(m->rstd, (size_t)Tp * f))) return rc;
   if ((rc = ensure(m->qpad, (size_t)Tp * f))) return rc;
+  if ((rc = ensure(m->part, (size_t)(c.head_hidden / 128) * Tp * 2 * f))) return rc;
   m->Tp_cap = Tp;
   return DC_OK;
 }
@@ -273,6 +276,8 @@ int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, con
   g.N = N;
   g.Tp = m->Tp;
   g.gelu_tanh = m->cfg.gelu_tanh;
+  g.w3 = m->W3;
+  g.part = (float*)m->part.p;
   ProfScope ps(m, st, name);
   return launch_gemm(st, g, epi, ln);
 }
@@ -399,11 +404,15 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   const int64_t Tp = m->Tp;
 
   ProfScope whole(m, st, "forward");
+  static const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
+  const bool l0_table = !no_l0_table && m->u_table0 != nullptr;
   {
     ProfScope ps(m, st, "embed");
-    if ((rc = launch_embed(st, d_ids, ids_i64, d_quals, m->emb, c.vocab, D, m->d_blk_read, m->d_toff, m->d_src_base,
-                           m->d_ntok, Tp, x, qpad)))
-      return rc;
+    rc = l0_table ? launch_embed_l0(st, d_ids, ids_i64, d_quals, m->emb, m->u_table0, c.vocab, D, m->d_blk_read,
+                                    m->d_toff, m->d_src_base, m->d_ntok, Tp, x, u, qpad)
+                  : launch_embed(st, d_ids, ids_i64, d_quals, m->emb, c.vocab, D, m->d_blk_read, m->d_toff,
+                                 m->d_src_base, m->d_ntok, Tp, x, qpad);
+    if (rc) return rc;
   }
   // channels per workgroup of the long-convolution kernel: keep all four waves busy on short reads
   const int nchunk_min = (m->max_P + 3) / 4;
@@ -411,12 +420,15 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
 
   for (int li = 0; li < c.n_layer; ++li) {
     LayerDev& L = m->layers[li];
-    {
-      ProfScope ps(m, st, "ln_stats");
-      if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+    if (!(li == 0 && l0_table)) {  // layer 0: u was gathered from the per-token-id table by the embed kernel
+      {
+        ProfScope ps(m, st, "ln_stats");
+        if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+      }
+      if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, L.Wp_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D,
+                         3 * D)))
+        return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, L.Wp_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D, 3 * D)))
-      return rc;
     {
       HyenaArgs a{};
       a.u = u;
@@ -454,9 +466,20 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   }
   if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, m->Wp_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H)))
     return rc;
-  if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU, H, H)))
-    return rc;
-  {
+  static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
+  if (m->gemm_mode == 1 && !no_head_fuse) {
+    // linear2 + residual + ReLU + linear3 in one kernel: the 1024-wide activation never reaches HBM
+    if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
+                       H)))
+      return rc;
+    ProfScope ps(m, st, "head_out");
+    if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / 128, m->b3, Tp, m->d_blk_read, m->d_toff,
+                                 m->d_src_base, m->d_ntok, d_logits)))
+      return rc;
+  } else {
+    if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
+                       H, H)))
+      return rc;
     ProfScope ps(m, st, "head_out");
     if ((rc = launch_head_out(st, ob, m->W3, m->b3, H, c.num_class, Tp, m->d_blk_read, m->d_toff, m->d_src_base,
                               m->d_ntok, d_logits)))
@@ -504,6 +527,25 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     fold_transpose(lw.in_proj_w, lw.in_proj_b, lw.norm1_w, lw.norm1_b, 3 * D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_in));
     UP(upload_planes(m, Wt, D, 3 * D, &L.Wp_in));
+    if (li == 0) {
+      // u0[v][n] = b'[n] + sum_k Wt[k][n] * (emb[v][k] - mean_v) * rstd_v   (gamma / beta already folded), fp64
+      std::vector<float> tab((size_t)cfg->vocab * 3 * D);
+      for (int v = 0; v < cfg->vocab; ++v) {
+        const float* e = w->embedding + (size_t)v * D;
+        double mu = 0.0, var = 0.0;
+        for (int k = 0; k < D; ++k) mu += e[k];
+        mu /= D;
+        for (int k = 0; k < D; ++k) var += ((double)e[k] - mu) * ((double)e[k] - mu);
+        var /= D;
+        const double rstd = 1.0 / std::sqrt(var + (double)cfg->ln_eps);
+        for (int n = 0; n < 3 * D; ++n) {
+          double acc = bo[n];
+          for (int k = 0; k < D; ++k) acc += (double)Wt[(size_t)k * 3 * D + n] * (((double)e[k] - mu) * rstd);
+          tab[(size_t)v * 3 * D + n] = (float)acc;
+        }
+      }
+      UP(upload(m, tab, &m->u_table0));
+    }
     UP(upload(m, bo, &L.b_in));
     UP(upload_raw(m, lw.short_w, (size_t)3 * D * 3, &L.sw));
     UP(upload_raw(m, lw.short_b, (size_t)3 * D, &L.sb));
@@ -555,7 +597,7 @@ extern "C" void dc_model_free(dc_model* m) {
   for (void* p : m->owned) (void)hipFree(p);
   for (auto& L : m->layers)
     if (L.kf) (void)hipFree(L.kf);
-  for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx})
+  for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     if (b->p) (void)hipFree(b->p);
   if (m->pinned) (void)hipHostFree(m->pinned);
   if (m->staging_done) (void)hipEventDestroy(m->staging_done);
@@ -589,7 +631,7 @@ extern "C" int64_t dc_model_device_bytes(const dc_model* m) {
   if (!m) return 0;
   int64_t b = m->weight_bytes;
   b += (int64_t)m->layers.size() * m->cfg.d_model * m->kf_taps * (int64_t)sizeof(float);
-  for (const DevBuf* d : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx})
+  for (const DevBuf* d : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     b += (int64_t)d->bytes;
   return b;
 }

@@ -68,7 +68,7 @@ template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NI], int n_w0, int64_t t_w0, int i,
                                               int h) {
   // n_w0 / t_w0: first output channel / token of this wave's (32 MI) x (32 NI) sub-tile
-  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED);
   const int n0 = n_w0 + 4 * h;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         if (EPI == EPI_BIAS_RES) v += rv[e];
         if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
         if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
-        if (EPI == EPI_BIAS_RES_RELU) v = fmaxf(v + rv[e], 0.f);     // head.py:98
+        if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) v = fmaxf(v + rv[e], 0.f);  // head.py:98
 #ifdef DC_ABL_NOEPI
         asm volatile("" ::"v"(v));
 #else
@@ -282,7 +282,7 @@ static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][NI], float* patch, int n_w0,
                                                   int64_t t_w0, int lane) {
-  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU);
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED);
   const int i = lane & 31, h = lane >> 5;
   const int rr = lane >> 3, c4 = (lane & 7) * 4;  // read-back: row rr (+8 per pass), 4 tokens at column c4
 #pragma unroll
@@ -290,17 +290,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
     const int64_t t = t_w0 + ni * 32 + c4;
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI == EPI_BIAS_RELU_Q) qv = *reinterpret_cast<const float4*>(g.q + t);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};  // partial logits (EPI_HEAD2_FUSED)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[mi][ni][e];
       // same wave writes and reads the patch: LDS operations of one wave complete in order
       float4 v[4], rv[4];
-      float bias[4];
+      float bias[4], w30[4], w31[4];
 #pragma unroll
       for (int p4 = 0; p4 < 4; ++p4) {
         const int n = n_w0 + mi * 32 + p4 * 8 + rr;
         bias[p4] = g.bias[n];
+        if (EPI == EPI_HEAD2_FUSED) {
+          w30[p4] = g.w3[n];
+          w31[p4] = g.w3[g.N + n];
+        }
         if (RES) rv[p4] = *reinterpret_cast<const float4*>(g.R + (int64_t)n * g.Tp + t);
       }
 #pragma unroll
@@ -317,14 +322,38 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
           if (EPI == EPI_BIAS_RES) x += r4[c];
           if (EPI == EPI_BIAS_GELU) x = g.gelu_tanh ? gelu_tanh(x) : gelu_erf(x);
           if (EPI == EPI_BIAS_RELU_Q) x = fmaxf(x, 0.f) + q4[c];       // head.py:94,97
-          if (EPI == EPI_BIAS_RES_RELU) x = fmaxf(x + r4[c], 0.f);      // head.py:98
+          if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) x = fmaxf(x + r4[c], 0.f);  // head.py:98
           o[c] = x;
+          if (EPI == EPI_HEAD2_FUSED) {  // head.py:102: logits += W3[:, n] * o[n]
+            s0[c] = fmaf(x, w30[p4], s0[c]);
+            s1[c] = fmaf(x, w31[p4], s1[c]);
+          }
         }
+        if (EPI != EPI_HEAD2_FUSED) {
 #ifdef DC_ABL_NOEPI
-        asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
 #else
-        *reinterpret_cast<float4*>(g.C + (int64_t)n * g.Tp + t) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(g.C + (int64_t)n * g.Tp + t) = make_float4(o[0], o[1], o[2], o[3]);
 #endif
+        }
+        (void)n;
+      }
+    }
+    if (EPI == EPI_HEAD2_FUSED) {
+      // rows of a token are spread over the lanes with equal (lane & 7): fixed-order butterfly, deterministic
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int d = 8; d <= 32; d <<= 1) {
+          s0[c] += __shfl_xor(s0[c], d, 64);
+          s1[c] += __shfl_xor(s1[c], d, 64);
+        }
+      }
+      if (rr == 0) {
+        const int nb = n_w0 / G_BN;
+        float* pp = g.part + ((int64_t)nb * g.Tp + t) * 2;
+        *reinterpret_cast<float4*>(pp) = make_float4(s0[0], s1[0], s0[1], s1[1]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(s0[2], s1[2], s0[3], s1[3]);
       }
     }
   }
@@ -499,6 +528,9 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln) {
     switch (epi) {
       case EPI_BIAS_RES: return launch_gemm_t<EPI_BIAS_RES, false>(st, g);
       case EPI_BIAS_RES_RELU: return launch_gemm_t<EPI_BIAS_RES_RELU, false>(st, g);
+      case EPI_HEAD2_FUSED:
+        DC_REQUIRE(g.Wp && g.w3 && g.part, "EPI_HEAD2_FUSED needs the bf16x6 path, w3 and part");
+        return launch_gemm_t<EPI_HEAD2_FUSED, false>(st, g);
       default: break;
     }
   }
@@ -971,6 +1003,91 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
   out.x = acc0 + b3[0];
   out.y = acc1 + b3[1];
   *reinterpret_cast<float2*>(logits + (src_base[r] + l) * 2) = out;
+}
+
+// logits[t] = b3 + sum over the n_part channel blocks of the fused linear3 partials (fixed order)
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int n_part,
+                                                          const float* __restrict__ b3, int64_t Tp,
+                                                          const int32_t* __restrict__ blk_read,
+                                                          const int32_t* __restrict__ toff,
+                                                          const int64_t* __restrict__ src_base,
+                                                          const int32_t* __restrict__ ntok,
+                                                          float* __restrict__ logits) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tp) return;
+  const int r = blk_read[t >> 5];
+  if (r < 0) return;
+  const int l = (int)(t - toff[r]);
+  if (l >= ntok[r]) return;
+  float2 acc = make_float2(b3[0], b3[1]);
+  for (int nb = 0; nb < n_part; ++nb) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((int64_t)nb * Tp + t) * 2);
+    acc.x += v.x;
+    acc.y += v.y;
+  }
+  *reinterpret_cast<float2*>(logits + (src_base[r] + l) * 2) = acc;
+}
+
+int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
+                       const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
+                       float* logits) {
+  hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((Tp + 255) / 256)), dim3(256), 0, st, part, n_part, b3, Tp,
+                     blk_read, toff, src_base, ntok, logits);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+// Embedding + layer-0 in_proj in one gather: in_proj(LayerNorm(emb[id])) only depends on the token id, so
+// the first layer's u = x0|x1|v rows come from a [vocab][3D] table built at load time.
+template <typename IdT>
+__global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ ids, const float* __restrict__ quals,
+                                                       const float* __restrict__ emb,
+                                                       const float* __restrict__ u_table, int vocab, int D,
+                                                       const int32_t* __restrict__ blk_read,
+                                                       const int32_t* __restrict__ toff,
+                                                       const int64_t* __restrict__ src_base,
+                                                       const int32_t* __restrict__ ntok, int64_t Tp,
+                                                       float* __restrict__ x, float* __restrict__ u,
+                                                       float* __restrict__ qpad) {
+  extern __shared__ float s_tab[];  // [vocab][D] then [vocab][3D]
+  float* s_emb = s_tab;
+  float* s_u = s_tab + vocab * D;
+  for (int j = threadIdx.x; j < vocab * D; j += 256) s_emb[j] = emb[j];
+  for (int j = threadIdx.x; j < vocab * 3 * D; j += 256) s_u[j] = u_table[j];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tp) return;
+  const int r = blk_read[t >> 5];
+  int id = -1;
+  float qv = 0.f;
+  if (r >= 0) {
+    const int l = (int)(t - toff[r]);
+    if (l < ntok[r]) {
+      const int64_t sidx = src_base[r] + l;
+      id = (int)ids[sidx];
+      qv = quals[sidx];
+      if (id < 0 || id >= vocab) id = -1;
+    }
+  }
+  qpad[t] = qv;
+  for (int c = 0; c < D; ++c) x[(int64_t)c * Tp + t] = id >= 0 ? s_emb[id * D + c] : 0.f;
+  for (int c = 0; c < 3 * D; ++c) u[(int64_t)c * Tp + t] = id >= 0 ? s_u[id * 3 * D + c] : 0.f;
+}
+
+int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
+                    const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
+                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad) {
+  const unsigned grid = (unsigned)((Tp + 255) / 256);
+  const size_t lds = (size_t)vocab * D * 4 * sizeof(float);
+  DC_REQUIRE(lds <= 64 * 1024, "embedding tables do not fit the default LDS allocation");
+  if (ids_i64)
+    hipLaunchKernelGGL(embed_l0_kernel<int64_t>, dim3(grid), dim3(256), lds, st, (const int64_t*)ids, quals, emb,
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad);
+  else
+    hipLaunchKernelGGL(embed_l0_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)ids, quals, emb,
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
 }
 
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
