@@ -37,6 +37,9 @@ FLOPS_PER_TOKEN_TOTAL = 8_916_992
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 DOMINANT = "gemm_head2"       # head linear2 (1024x1024): 23.5 % of the algorithmic flops, one launch / step
+# HBM (L2-miss) bytes per token of the dominant kernel from the PMC passes committed in
+# profiles/r01_pmc_hbm_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / tokens, gfx950 correction applied.
+PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024}
 
 
 def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
@@ -176,6 +179,11 @@ def main():
                     "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_ms": stages[DOMINANT]["avg_ms"],
                     "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[DOMINANT] * tokens_per_launch}
+            if args.gemm_mode in PMC_TRAFFIC_BYTES_PER_TOKEN:
+                padded = -(-tokens_per_launch // 256) * 256
+                roof["traffic"] = int(PMC_TRAFFIC_BYTES_PER_TOKEN[args.gemm_mode] * padded)
+                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["algorithmic_hbm_bytes_per_launch"] = int(padded * (2 * 1024 * 4 + 16))  # B operand + residual, fp32
             if args.gemm_mode == "bf16x6":
                 roof["executed_frac"] = round(6 * ach / peak, 4)
                 roof["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)

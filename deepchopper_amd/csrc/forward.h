@@ -59,6 +59,7 @@ struct HyenaArgs {
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
+int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (partials of EPI_HEAD2_FUSED)
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);

@@ -473,7 +473,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
                        H)))
       return rc;
     ProfScope ps(m, st, "head_out");
-    if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / 128, m->b3, Tp, m->d_blk_read, m->d_toff,
+    if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / gemm6_channel_block(), m->b3, Tp, m->d_blk_read, m->d_toff,
                                  m->d_src_base, m->d_ntok, d_logits)))
       return rc;
   } else {

@@ -242,7 +242,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int H_BK = DC_H_BK;      // k-tile depth
 constexpr int H_OPT = H_BK / 8;    // k-octets per tile
-constexpr int H_A_BYTES = 3 * H_BK * G_BN * 2;
 
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& mm, bf16x8& ll) {
 #pragma unroll
@@ -262,15 +261,19 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 #ifndef DC_H_STAGES
 #define DC_H_STAGES 2
 #endif
+#ifndef DC_H_BN
+#define DC_H_BN 128   // output channels per block
+#endif
 #ifndef DC_H_BT
 #define DC_H_BT 256   // tokens per block
 #endif
 #ifndef DC_H_NW
-#define DC_H_NW 8     // waves per block; every wave owns all 128 output channels x 32 tokens
+#define DC_H_NW 8     // waves per block; every wave owns all H_BN output channels x 32 tokens
 #endif
-constexpr int H_BT = DC_H_BT, H_NW = DC_H_NW;
-constexpr int H_MI = G_BN / 32;            // 4 accumulator tiles down the channel axis
+constexpr int H_BN = DC_H_BN, H_BT = DC_H_BT, H_NW = DC_H_NW;
+constexpr int H_MI = H_BN / 32;            // accumulator tiles down the channel axis
 constexpr int H_NI = H_BT / (32 * H_NW);   // tiles along the token axis per wave
+constexpr int H_A_BYTES = 3 * H_BK * H_BN * 2;
 constexpr int H_B_BYTES = H_BK * H_BT * 4;
 static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered by the waves");
 
@@ -350,7 +353,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
         }
       }
       if (rr == 0) {
-        const int nb = n_w0 / G_BN;
+        const int nb = n_w0 / (32 * MI);  // one partial per channel block of this kernel's tile height
         float* pp = g.part + ((int64_t)nb * g.Tp + t) * 2;
         *reinterpret_cast<float4*>(pp) = make_float4(s0[0], s1[0], s0[1], s1[1]);
         *reinterpret_cast<float4*>(pp + 4) = make_float4(s0[2], s1[2], s0[3], s1[3]);
@@ -373,10 +376,10 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int n_blocks = g.N / G_BN;
+  const int n_blocks = g.N / H_BN;
   const int nb = bid % n_blocks;
   const int64_t tb = bid / n_blocks;
-  const int n_blk = nb * G_BN;
+  const int n_blk = nb * H_BN;
   const int64_t t_blk = tb * H_BT;
 
   const int tid = threadIdx.x;
@@ -385,10 +388,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   const int t_w = wave * (32 * H_NI);  // wave origin inside the block tile (all 128 channels)
   const int i = lane & 31, h = lane >> 5;
 
-  // LDS image per buffer: A planes [3][H_OPT][128 n][8 bf16] then B [H_BK][H_BT] fp32
+  // LDS image per buffer: A planes [3][H_OPT][H_BN n][8 bf16] then B [H_BK][H_BT] fp32
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
-  // one LDS-DMA instruction moves 1 KiB: half a 128-channel A chunk, or 256 floats of the B tile
-  constexpr int A_INSTR = 3 * H_OPT * 2;
+  // one LDS-DMA instruction moves 1 KiB: 64 channels x 8 k of one A plane, or 256 floats of the B tile
+  constexpr int A_SEG = H_BN / 64;  // 1 KiB segments per (plane, octet) chunk
+  constexpr int A_INSTR = 3 * H_OPT * A_SEG;
   constexpr int B_INSTR = H_B_BYTES / 1024;
   // LDS-DMA instructions per wave and k-tile, rounded DOWN: waves that issue one more only wait a little
   // longer than needed (waiting for fewer outstanding operations is always safe)
@@ -400,10 +404,10 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   auto stage = [&](int buf, int kt) {
     for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
       if (q < A_INSTR) {
-        const int pl = q / (2 * H_OPT), o = (q >> 1) % H_OPT, half = q & 1;
+        const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
         const unsigned short* src =
-            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + half * 64 + lane) << 3);
-        glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * 128 + half * 64) * 16);
+            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + seg * 64 + lane) << 3);
+        glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * H_BN + seg * 64) * 16);
       } else {
         const int bq = q - A_INSTR;
         const int row = (H_BT >= 256) ? (bq * 256) / H_BT : bq * B_ROWS_PER_INSTR + b_row_l;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
       for (int mi = 0; mi < H_MI; ++mi) {
         bf16x8 af[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * 128 + mi * 32 + i];
+        for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
 #pragma unroll
         for (int ni = 0; ni < H_NI; ++ni) {
           f32x16 c = acc[mi][ni];
@@ -506,14 +510,16 @@ template <int EPI, bool LN>
 static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
   const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
   if (g.Wp) {
-    DC_REQUIRE(g.K % H_BK == 0 && g.Tp % H_BT == 0, "shape not aligned to the bf16x6 tile");
-    const unsigned grid6 = (unsigned)((g.N / G_BN) * (g.Tp / H_BT));
+    DC_REQUIRE(g.K % H_BK == 0 && g.Tp % H_BT == 0 && g.N % H_BN == 0, "shape not aligned to the bf16x6 tile");
+    const unsigned grid6 = (unsigned)((g.N / H_BN) * (g.Tp / H_BT));
     hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
   } else
     hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
+
+int gemm6_channel_block() { return H_BN; }
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln) {
   DC_REQUIRE(g.N % G_BN == 0 && g.K % G_BK == 0 && g.Tp % G_BT == 0, "gemm shape not tile aligned");
