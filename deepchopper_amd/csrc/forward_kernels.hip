@@ -812,8 +812,12 @@ __global__ __launch_bounds__(256) void hyena_kernel(HyenaArgs a) {
 // p' = 32 oc + w, w+4, ... (8 tiles) and adds T_{p'-p} Z[p] for every owned p' >= p.
 // -------------------------------------------------------------------------------------
 constexpr int HY_ZSTRIDE = 36;  // floats per read row of the z tile: 16-B aligned rows, conflict-free b128 reads
+#ifndef DC_HY_NW
+#define DC_HY_NW 4   // waves per workgroup; wave w owns output blocks w, w + NW, ... of the 32-block chunk
+#endif
+constexpr int HY_NW = DC_HY_NW, HY_ACC = 32 / HY_NW;
 
-__global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
+__global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_kernel(HyenaArgs a) {
   extern __shared__ float s_mem[];
   const int g = blockIdx.x;
   const int c = blockIdx.y;
@@ -832,11 +836,12 @@ __global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
 
   {
     const float* krow = a.kf + (int64_t)c * a.kf_stride;
-    for (int j = tid; j < 32 + ktaps; j += 256) s_k[j] = j < 32 ? 0.f : krow[j - 32];
+    for (int j = tid; j < 32 + ktaps; j += 64 * HY_NW) s_k[j] = j < 32 ? 0.f : krow[j - 32];
   }
 
-  // ---- producer role: thread -> (read zr, 4 steps zq4 .. zq4+3) of the z tile ----
-  const int zr = tid >> 3, zq4 = (tid & 7) * 4;
+  // ---- producer role (first 256 threads): thread -> (read zr, 4 steps zq4 .. zq4+3) of the z tile ----
+  const bool producer = tid < 256;
+  const int zr = (tid & 255) >> 3, zq4 = (tid & 7) * 4;
   int rz = a.grp_reads[g * 32 + zr];
   const bool z_valid = rz >= 0;
   if (!z_valid) rz = a.grp_reads[g * 32];
@@ -851,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
 
   auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
     l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < z_nblk) {
+    if (producer && p < z_nblk) {
       const int64_t t = 32 * p + zq4;
       if (t > 0) {
         l1 = *reinterpret_cast<const float4*>(ux1 + t - 4);
@@ -870,12 +875,12 @@ __global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
     z.z = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
     z.w = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
     if (!act) z = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(s_z + (p & 1) * (32 * HY_ZSTRIDE) + zr * HY_ZSTRIDE + zq4) = z;
+    if (producer) *reinterpret_cast<float4*>(s_z + (p & 1) * (32 * HY_ZSTRIDE) + zr * HY_ZSTRIDE + zq4) = z;
   };
 
-  f32x16 acc[8];
+  f32x16 acc[HY_ACC];
 #pragma unroll
-  for (int m = 0; m < 8; ++m)
+  for (int m = 0; m < HY_ACC; ++m)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 
@@ -903,8 +908,8 @@ __global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
       zf[4 * j + 3] = v.w;
     }
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int pp = p_out0 + wave + 4 * m;  // owned output block (wave-uniform)
+    for (int m = 0; m < HY_ACC; ++m) {
+      const int pp = p_out0 + wave + HY_NW * m;  // owned output block (wave-uniform)
       if (pp >= p && pp <= p_last) {
         const int base = 32 + 32 * (pp - p) + n - 16 * h;
         float af[16];
@@ -929,8 +934,8 @@ __global__ __launch_bounds__(256, 2) void hyena2_kernel(HyenaArgs a) {
   float* yrow = a.y + (int64_t)c * a.Tp + off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    const int pp = p_out0 + wave + 4 * m;
+  for (int m = 0; m < HY_ACC; ++m) {
+    const int pp = p_out0 + wave + HY_NW * m;
     if (pp <= p_last && pp < my_nblk) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -962,7 +967,7 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
     DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena2_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(hyena2_kernel, dim3(n_groups, a.D, n_oc), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(hyena2_kernel, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

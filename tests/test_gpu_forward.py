@@ -183,3 +183,44 @@ def test_gemm_modes_error_vs_float64(hip_lib):
     print("max |logit - float64 oracle|:", {k: float(v) for k, v in errs.items()})
     assert errs["f32"] < 1e-4 and errs["bf16x6"] < 1e-4
     assert errs["bf16x6"] < 4 * max(errs["f32"], errs["oracle_f32"]) + 1e-6
+
+
+@pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001)])
+def test_forward_long_reads_match_oracle(env, B, L):
+    """BASELINE configs 3 and 4: 2 kb reads and reads up to 10 kb (several 32-block output chunks of the
+    long-convolution kernel, filters longer than one LDS chunk)."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(L)
+    ids, q = _inputs(rng, B, L)
+    ref = fr.forward(sd, ids, q).numpy()
+    out = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q)).cpu().numpy()
+    _check(out, ref)
+
+
+def test_forward_ragged_mixed_lengths_config4(env):
+    """Config 4 shape: log-uniform lengths 100 bp - 10 kb in one ragged batch (groups of 32 reads sorted by
+    length inside the long-convolution kernel); spot-check reads of every size class against the oracle."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(4)
+    lens = np.exp(rng.uniform(np.log(100), np.log(10000), 70)).astype(int) + 1
+    lens[:3] = [101, 10001, 3333]
+    B, stride = len(lens), int(lens.max())
+    ids = np.full((B, stride), 4, np.uint8)
+    q = np.zeros((B, stride), np.float32)
+    first = np.zeros(B, np.int32)
+    for b, n in enumerate(lens):
+        i1, q1 = _inputs(rng, 1, int(n))
+        first[b] = stride - n
+        ids[b, stride - n:] = i1[0]
+        q[b, stride - n:] = q1[0]
+    out = model.forward_ragged(ops.to_device(ids), ops.to_device(q), first, lens.astype(np.int32)).cpu().numpy()
+    assert np.isfinite(out).all()
+    order = np.argsort(lens)
+    for b in [0, 1, 2, int(order[0]), int(order[len(order) // 2]), int(order[-1])]:
+        n = int(lens[b])
+        ref = fr.forward(sd, ids[b: b + 1, stride - n:].astype(np.int64), q[b: b + 1, stride - n:]).numpy()[0]
+        _check(out[b, stride - n:], ref)
