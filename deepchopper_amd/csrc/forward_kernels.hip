@@ -12,6 +12,8 @@
 //   * the Hyena long convolution reads each (read, channel) sequence contiguously.
 //
 // Arithmetic: fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain).
+#include <cstdlib>
+
 #include "dc_common.h"
 #include "forward.h"
 
@@ -70,11 +72,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
   // n_w0 / t_w0: first output channel / token of this wave's (32 MI) x (32 NI) sub-tile
   constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED);
   const int n0 = n_w0 + 4 * h;
+  float s0[NI], s1[NI];  // partial logits per token column (EPI_HEAD2_FUSED)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) s0[ni] = s1[ni] = 0.f;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    float4 bv[4];
+    float4 bv[4], w30[4], w31[4];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) bv[q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bv[q4] = *reinterpret_cast<const float4*>(g.bias + n0 + mi * 32 + 8 * q4);
+      if (EPI == EPI_HEAD2_FUSED) {
+        w30[q4] = *reinterpret_cast<const float4*>(g.w3 + n0 + mi * 32 + 8 * q4);
+        w31[q4] = *reinterpret_cast<const float4*>(g.w3 + g.N + n0 + mi * 32 + 8 * q4);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int64_t t = t_w0 + ni * 32 + i;
@@ -97,11 +108,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
         if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
         if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) v = fmaxf(v + rv[e], 0.f);  // head.py:98
+        if (EPI == EPI_HEAD2_FUSED) {  // head.py:102, linear3 fused: logits += W3[:, n] * o[n]
+          const float4 a4 = w30[e >> 2], c4 = w31[e >> 2];
+          const float wa = (e & 3) == 0 ? a4.x : (e & 3) == 1 ? a4.y : (e & 3) == 2 ? a4.z : a4.w;
+          const float wc = (e & 3) == 0 ? c4.x : (e & 3) == 1 ? c4.y : (e & 3) == 2 ? c4.z : c4.w;
+          s0[ni] = fmaf(v, wa, s0[ni]);
+          s1[ni] = fmaf(v, wc, s1[ni]);
+        } else {
 #ifdef DC_ABL_NOEPI
-        asm volatile("" ::"v"(v));
+          asm volatile("" ::"v"(v));
 #else
-        cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
+          cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
 #endif
+        }
+      }
+    }
+  }
+  if (EPI == EPI_HEAD2_FUSED) {
+    // the two lane halves hold disjoint channel rows of the same token: one fixed-order exchange
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float a = s0[ni] + __shfl_xor(s0[ni], 32, 64);
+      const float c = s1[ni] + __shfl_xor(s1[ni], 32, 64);
+      if (h == 0) {
+        const int nb = n_w0 / (32 * MI);
+        *reinterpret_cast<float2*>(g.part + ((int64_t)nb * g.Tp + t_w0 + ni * 32 + i) * 2) = make_float2(a, c);
       }
     }
   }
@@ -260,6 +291,9 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 
 #ifndef DC_H_STAGES
 #define DC_H_STAGES 2
+#endif
+#ifndef DC_H_PERSIST_DEFAULT
+#define DC_H_PERSIST_DEFAULT 3
 #endif
 #ifndef DC_H_BN
 #define DC_H_BN 128   // output channels per block
@@ -506,13 +540,154 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 #endif
 }
 
+// Persistent variant of gemm6 for the short-K (K = 256) GEMMs: a workgroup walks several output tiles
+// and requests the first k-tile of its next tile while the last k-tile of the current one is consumed,
+// so the LDS-DMA stream never drains at tile boundaries (no exposed prologue latency per tile).
+// Tiles are dealt per XCD (n fastest) so the blocks of one XCD work on the same token panels.
+template <int EPI, bool LN>
+__global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs g) {
+  constexpr int BUF = H_A_BYTES + H_B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * BUF];
+
+  const int n_blocks = g.N / H_BN;
+  const unsigned total = (unsigned)n_blocks * (unsigned)(g.Tp / H_BT);
+  // contiguous logical tile range of this block's XCD, then round-robin over the XCD's blocks
+  const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const unsigned q8 = total >> 3, r8 = total & 7u;
+  const unsigned x_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const unsigned x_n = q8 + (xcd < r8 ? 1u : 0u);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_w = wave * (32 * H_NI);
+  const int i = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
+  constexpr int A_SEG = H_BN / 64;
+  constexpr int A_INSTR = 3 * H_OPT * A_SEG;
+  constexpr int B_INSTR = H_B_BYTES / 1024;
+  const int K8 = g.K >> 3;
+  const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
+  constexpr int B_ROWS_PER_INSTR = 256 / H_BT > 0 ? 256 / H_BT : 1;
+  auto stage = [&](int buf, int n_blk, int64_t t_blk, int kt) {
+    for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
+      if (q < A_INSTR) {
+        const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
+        const unsigned short* src =
+            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + seg * 64 + lane) << 3);
+        glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * H_BN + seg * 64) * 16);
+      } else {
+        const int bq = q - A_INSTR;
+        const int row = (H_BT >= 256) ? (bq * 256) / H_BT : bq * B_ROWS_PER_INSTR + b_row_l;
+        const int col = (H_BT >= 256) ? (bq * 256) % H_BT + lane * 4 : b_col_l;
+        const float* src = g.X + ((int64_t)kt * H_BK + row) * g.Tp + t_blk + col;
+        glds16(src, lds0 + buf * BUF + H_A_BYTES + bq * 1024);
+      }
+    }
+  };
+  const int nk = g.K / H_BK;
+  if (jb >= x_n) return;  // block-uniform: fewer tiles than blocks on this XCD
+
+  unsigned loc = jb;
+  int n_blk = (int)((x_lo + loc) % n_blocks) * H_BN;
+  int64_t t_blk = (int64_t)((x_lo + loc) / n_blocks) * H_BT;
+  stage(0, n_blk, t_blk, 0);
+  int cur = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  while (true) {
+    const unsigned loc_next = loc + per_xcd;
+    const bool has_next = loc_next < x_n;
+    const int n_next = has_next ? (int)((x_lo + loc_next) % n_blocks) * H_BN : 0;
+    const int64_t t_next = has_next ? (int64_t)((x_lo + loc_next) / n_blocks) * H_BT : 0;
+
+    float rs[H_NI], nm[H_NI];
+#pragma unroll
+    for (int ni = 0; ni < H_NI; ++ni) {
+      rs[ni] = 1.f;
+      nm[ni] = 0.f;
+      if (LN) {
+        const int64_t t = t_blk + t_w + ni * 32 + i;
+        const float m = g.mean[t], r = g.rstd[t];
+        rs[ni] = r;
+        nm[ni] = -m * r;
+      }
+    }
+    f32x16 acc[H_MI][H_NI];
+#pragma unroll
+    for (int a = 0; a < H_MI; ++a)
+#pragma unroll
+      for (int b = 0; b < H_NI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage(cur ^ 1, n_blk, t_blk, kt + 1);
+      else if (has_next) stage(cur ^ 1, n_next, t_next, 0);  // first k-tile of the next output tile
+      const unsigned char* bufp = smem6 + cur * BUF;
+      const bf16x8* pA = reinterpret_cast<const bf16x8*>(bufp);
+      const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
+#pragma unroll
+      for (int s = 0; s < H_BK / 16; ++s) {
+        bf16x8 bh[H_NI], bm[H_NI], bl[H_NI];
+#pragma unroll
+        for (int ni = 0; ni < H_NI; ++ni) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
+            x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
+          }
+          split3(x, bh[ni], bm[ni], bl[ni]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < H_MI; ++mi) {
+          bf16x8 af[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
+#pragma unroll
+          for (int ni = 0; ni < H_NI; ++ni) {
+            f32x16 c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bh[ni], c, 0, 0, 0);  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bm[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bl[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bh[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bm[ni], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bh[ni], c, 0, 0, 0);
+            acc[mi][ni] = c;
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    // no LDS-DMA in flight here; buffer `cur` already holds the next tile's first k-tile
+    gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
+    if (!has_next) break;
+    loc = loc_next;
+    n_blk = n_next;
+    t_blk = t_next;
+  }
+}
+
 template <int EPI, bool LN>
 static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
   const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
   if (g.Wp) {
     DC_REQUIRE(g.K % H_BK == 0 && g.Tp % H_BT == 0 && g.N % H_BN == 0, "shape not aligned to the bf16x6 tile");
     const unsigned grid6 = (unsigned)((g.N / H_BN) * (g.Tp / H_BT));
-    hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
+    static const int persist = getenv("DC_GEMM_PERSIST") ? atoi(getenv("DC_GEMM_PERSIST")) : DC_H_PERSIST_DEFAULT;
+    // persist: 0 = one tile per workgroup, 1 = persistent for K <= 256, 2 = persistent for every GEMM,
+    // 3 = measured best per epilogue: persistent (direct epilogue) except for the GELU and fused-head epilogues
+    if ((persist == 1 && g.K <= 256) || persist == 2 ||
+        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED)) {
+      unsigned gp = 256u * DC_H_OCC;  // one wave of workgroups: occupancy x 256 CUs (multiple of 8)
+      if (gp > grid6) gp = (grid6 + 7u) & ~7u;
+      hipLaunchKernelGGL((gemm6p_kernel<EPI, LN>), dim3(gp), dim3(64 * H_NW), 0, st, g);
+    } else
+      hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
   } else
     hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
   DC_LAUNCH_CHECK();
