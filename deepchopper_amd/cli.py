@@ -64,10 +64,17 @@ def _predict(args) -> int:
         os.makedirs(out_dir / "0", exist_ok=True)
         tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w")
     n_batches = 0
-    for b0 in range(0, len(mine), per_dev):
+    if args.native:
+        # zero-padding batches bounded by a token budget (mixed-length reads, BASELINE config 4)
+        from .batcher import token_budget_batches
+
+        ranges = list(token_budget_batches([len(r[1]) for r in mine], args.max_tokens, args.max_reads))
+    else:
+        ranges = [(b0, min(b0 + per_dev, len(mine))) for b0 in range(0, len(mine), per_dev)]
+    for b0, b1 in ranges:
         if args.limit_batches is not None and n_batches >= args.limit_batches:
             break
-        chunk = mine[b0: b0 + per_dev]
+        chunk = mine[b0:b1]
         ids = [r[0] for r in chunk]
         reads, res = pipe.predict_reads(ids, [r[1] for r in chunk], [r[2] for r in chunk],
                                         reference_padding=not args.native)
@@ -96,9 +103,37 @@ def main(argv=None) -> int:
     p.add_argument("--max-sample", type=int, default=None, help="Maximum number of samples to process")
     p.add_argument("--verbose", "-v", action="store_true", help="Enable verbose output")
     p.add_argument("--native", action="store_true", help="zero-padding batches + per-read intervals TSV")
+    p.add_argument("--max-tokens", type=int, default=2_000_000, help="token budget per --native batch")
+    p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native batch (-b applies to reference batches)")
+    c = sub.add_parser("chop", help="DeepChopper: chop the given predictions!")
+    c.add_argument("predicts", nargs="+", help="Paths to prediction folders ({out}/0)")
+    c.add_argument("fq", help="Path to FASTQ file")
+    c.add_argument("--smooth-window", type=int, default=21)
+    c.add_argument("--min-interval-size", type=int, default=13)
+    c.add_argument("--approved-intervals", type=int, default=20)
+    c.add_argument("--max-process-intervals", type=int, default=4)
+    c.add_argument("--min-read-length", type=int, default=20)
+    c.add_argument("--chop-type", default="all", choices=["terminal", "internal", "all"])
+    c.add_argument("--output", "-o", default=None, help="Output prefix")
+    c.add_argument("--max-batch", type=int, default=None)
+    c.add_argument("--chunk-size", type=int, default=10000)
+    c.add_argument("--threads", "-t", type=int, default=2, help="unused: smoothing runs on the GPU")
+    c.add_argument("--verbose", "-v", action="store_true")
     args = ap.parse_args(argv)
     if args.verbose:
         logging.basicConfig(level=logging.INFO, format="%(message)s")
+    if args.cmd == "chop":
+        from . import _lib
+        from .chop import chop
+        from .predict import SmoothParams
+
+        _lib.require_gpu()
+        sp = SmoothParams(window=args.smooth_window, min_interval=args.min_interval_size,
+                          approved=args.approved_intervals, max_process_intervals=args.max_process_intervals,
+                          min_read_length_after_chop=args.min_read_length)
+        path = chop(args.predicts, args.fq, sp, args.chop_type, args.output, args.chunk_size, args.max_batch)
+        print(path)
+        return 0
     return _predict(args)
 
 

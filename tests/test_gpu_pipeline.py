@@ -118,15 +118,65 @@ def test_cli_predict(env, tmp_path):
     out = tmp_path / "predictions"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "deepchopper_amd.cli", "predict", str(fq), "-g", "1", "-o", str(out), "-b", "12",
-           "-m", str(ckpt.parent), "--native"]
+           "-m", str(ckpt.parent)]
     proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stderr[-2000:]
-    files = sorted(os.listdir(out / "0"))
-    assert files == ["0.intervals.tsv", "0_0.pt", "0_1.pt", "0_2.pt"]
-    lines = (out / "0" / "0.intervals.tsv").read_text().strip().split("\n")
-    assert [l.split("\t")[0] for l in lines] == ids
+    assert sorted(os.listdir(out / "0")) == ["0_0.pt", "0_1.pt", "0_2.pt"]  # reference batching: 12 + 12 + 6
     d = torch.load(out / "0" / "0_2.pt", weights_only=True)
     assert d["prediction"].shape[0] == 6
+    out2 = tmp_path / "native"
+    cmd2 = cmd[:7] + ["-o", str(out2)] + cmd[9:] + ["--native", "--max-reads", "16"]
+    proc = subprocess.run(cmd2, cwd=root, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert sorted(os.listdir(out2 / "0")) == ["0.intervals.tsv", "0_0.pt", "0_1.pt"]  # token-budget batches: 16 + 14
+    lines = (out2 / "0" / "0.intervals.tsv").read_text().strip().split("\n")
+    assert [l.split("\t")[0] for l in lines] == ids
     # no-GPU flag is rejected loudly
     proc = subprocess.run(cmd[:5] + ["-g", "0"], cwd=root, capture_output=True, text=True, timeout=120)
     assert proc.returncode != 0 and "no CPU fallback" in proc.stderr
+
+
+def test_chop_driver_matches_oracle(env, tmp_path):
+    """predict -> .pt -> chop end to end; every output record equals the oracle's `chop_read`
+    (gating S4, intervals S3, complement S5, record naming S6)."""
+    torch, sd, pipe = env
+    import gzip
+
+    from deepchopper_amd import rs_api, synth
+    from deepchopper_amd.chop import chop
+    from deepchopper_amd.fastq import iter_fastq
+    from deepchopper_amd.predict import write_pt_batch
+    from oracle import dc_oracle as o
+
+    seq, qual, ids = synth.synth_reads_fixed(36, 600, seed=42)
+    short = synth.synth_reads_fixed(4, 100, seed=9, start_index=900)  # < 150 bp: passed through
+    seqs = [s.tobytes() for s in seq] + [s.tobytes() for s in short[0]]
+    quals = [q.tobytes() for q in qual] + [q.tobytes() for q in short[1]]
+    ids = ids + short[2]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    pdir = tmp_path / "pred" / "0"
+    for b, b0 in enumerate(range(0, len(ids), 12)):
+        sl = slice(b0, b0 + 12)
+        _, res = pipe.predict_reads(ids[sl], seqs[sl], quals[sl], reference_padding=True)
+        write_pt_batch(str(pdir / f"0_{b}.pt"), res, ids[sl])
+    # synthetic weights give noisy labels -> use a permissive interval policy so that reads really get chopped
+    from deepchopper_amd.predict import SmoothParams
+
+    sp = SmoothParams(window=21, min_interval=5, approved=40, max_process_intervals=40)
+    os.chdir(tmp_path)
+    out = chop([str(pdir)], str(fq), sp)
+    preds = rs_api.load_predicts_from_batch_pts(str(pdir))
+    assert os.path.basename(out).startswith(f"reads.{len(preds)}pd.") and out.endswith("record.chop.fq.gz")
+    got = list(iter_fastq(out))
+    exp = []
+    n_chopped = 0
+    for rid, s, q in zip(ids, seqs, quals):
+        p = preds[rid]
+        recs = o.chop_read(o.Predict(np.asarray(p.prediction, np.int8), p.seq, rid, p.is_truncated), rid.encode(), s, q,
+                           21, 5, 40, 40, 20, "all")
+        n_chopped += len(recs) != 1 or recs[0][0] != rid.encode()
+        exp += [(r[0].decode(), r[1], r[2]) for r in recs]
+    assert n_chopped > 5, "the test should exercise real chopping"
+    assert got == exp
+    assert int(os.path.basename(out).split(".")[2].replace("record", "")) == len(got)
