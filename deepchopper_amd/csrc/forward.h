@@ -12,6 +12,9 @@ enum GemmEpilogue {
   EPI_BIAS_RELU_Q,    // C = relu(acc + bias) + q[t]                      (head linear1 + quality residual)
   EPI_BIAS_RES_RELU,  // C = relu(acc + bias + R)                         (head linear2 + residual)
   EPI_HEAD2_FUSED,    // o = relu(acc + bias + R) is not stored: part[nb][t][:] = W3[:, n-block] . o   (linear3 fused)
+  EPI_BIAS_RES_STATS, // EPI_BIAS_RES + per-token sum / sum of squares of the result added into st_sum / st_sq
+                      // (LayerNorm statistics of the next layer fused into the producer; two channel blocks per
+                      // token -> two commutative atomic addends -> deterministic)
 };
 
 struct GemmArgs {
@@ -24,6 +27,10 @@ struct GemmArgs {
   const float* q;     // [Tp]    quality or nullptr
   const float* mean;  // [Tp]    LayerNorm statistics of X's tokens (LN variants)
   const float* rstd;  // [Tp]
+  float* st_sum;      // [Tp] out: sum over channels of the result (EPI_BIAS_RES_STATS), zeroed by the caller
+  float* st_sq;       // [Tp] out: sum of squares
+  int stats_are_sums; // LN prologue: mean[] / rstd[] hold sum / sum of squares over K channels (fused statistics)
+  float ln_eps;
   const float* w3;    // [2][N]  head linear3 weight (EPI_HEAD2_FUSED)
   float* part;        // [N/128][Tp][2] partial logits per 128-channel block (EPI_HEAD2_FUSED)
   int K, N;

@@ -261,7 +261,7 @@ struct ProfScope {
 
 int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, const unsigned short* Wp,
              const float* X, float* C, const float* bias, const float* R, const float* q, bool ln, int epi, int K,
-             int N) {
+             int N, bool stats_are_sums = false) {
   GemmArgs g{};
   g.Wt = Wt;
   g.Wp = m->gemm_mode == 1 ? Wp : nullptr;
@@ -278,6 +278,10 @@ int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, con
   g.gelu_tanh = m->cfg.gelu_tanh;
   g.w3 = m->W3;
   g.part = (float*)m->part.p;
+  g.st_sum = (float*)m->mean.p;  // the statistics buffers double as sum / sum-of-squares accumulators
+  g.st_sq = (float*)m->rstd.p;
+  g.stats_are_sums = stats_are_sums ? 1 : 0;
+  g.ln_eps = m->cfg.ln_eps;
   ProfScope ps(m, st, name);
   return launch_gemm(st, g, epi, ln);
 }
@@ -404,6 +408,10 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   const int64_t Tp = m->Tp;
 
   ProfScope whole(m, st, "forward");
+  static const bool no_fused_stats = getenv("DC_NO_FUSED_STATS") != nullptr;  // A/B switch
+  // bf16x6 mode with the layer-0 table: every LayerNorm input is produced by an out_proj / fc2 GEMM whose
+  // epilogue also accumulates the per-token sum and sum of squares -> no separate statistics pass
+  const bool fused_stats = !no_fused_stats && m->gemm_mode == 1;
   static const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
   const bool l0_table = !no_l0_table && m->u_table0 != nullptr;
   {
@@ -420,15 +428,21 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
 
   for (int li = 0; li < c.n_layer; ++li) {
     LayerDev& L = m->layers[li];
+    const bool sums = fused_stats && l0_table;  // statistics of x come from the previous producer's epilogue
     if (!(li == 0 && l0_table)) {  // layer 0: u was gathered from the per-token-id table by the embed kernel
-      {
+      if (!sums) {
         ProfScope ps(m, st, "ln_stats");
         if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
       }
       if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, L.Wp_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D,
-                         3 * D)))
+                         3 * D, sums)))
         return rc;
     }
+    auto zero_stats = [&]() -> int {
+      DC_HIP_CHECK(hipMemsetAsync(mean, 0, (size_t)Tp * sizeof(float), st));
+      DC_HIP_CHECK(hipMemsetAsync(rstd, 0, (size_t)Tp * sizeof(float), st));
+      return DC_OK;
+    };
     {
       HyenaArgs a{};
       a.u = u;
@@ -449,22 +463,29 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       if ((rc = old_hyena ? launch_hyena(st, a, m->n_groups, m->max_P) : launch_hyena2(st, a, m->n_groups, m->max_P)))
         return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false, EPI_BIAS_RES, D, D)))
+    if (sums && (rc = zero_stats())) return rc;
+    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false,
+                       sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, D, D)))
       return rc;
-    {
+    if (!sums) {
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, L.Wp_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D, DI)))
+    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, L.Wp_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D,
+                       DI, sums)))
       return rc;
-    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, L.Wp_fc2, hm, x, L.b_fc2, x, nullptr, false, EPI_BIAS_RES, DI, D)))
+    if (sums && (rc = zero_stats())) return rc;
+    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, L.Wp_fc2, hm, x, L.b_fc2, x, nullptr, false,
+                       sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, DI, D)))
       return rc;
   }
-  {
+  const bool head_sums = fused_stats && l0_table;
+  if (!head_sums) {
     ProfScope ps(m, st, "ln_stats");
     if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
   }
-  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, m->Wp_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H)))
+  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, m->Wp_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
+                     head_sums)))
     return rc;
   static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
   if (m->gemm_mode == 1 && !no_head_fuse) {

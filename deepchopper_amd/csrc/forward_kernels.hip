@@ -70,9 +70,10 @@ template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NI], int n_w0, int64_t t_w0, int i,
                                               int h) {
   // n_w0 / t_w0: first output channel / token of this wave's (32 MI) x (32 NI) sub-tile
-  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED);
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED) ||
+                       (EPI == EPI_BIAS_RES_STATS);
   const int n0 = n_w0 + 4 * h;
-  float s0[NI], s1[NI];  // partial logits per token column (EPI_HEAD2_FUSED)
+  float s0[NI], s1[NI];  // per token column: partial logits (EPI_HEAD2_FUSED) or sum / sum of squares (.._STATS)
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) s0[ni] = s1[ni] = 0.f;
 #pragma unroll
@@ -104,7 +105,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         const float4 b4 = bv[e >> 2];
         const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
         float v = acc[mi][ni][e] + bias;
-        if (EPI == EPI_BIAS_RES) v += rv[e];
+        if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS) v += rv[e];
+        if (EPI == EPI_BIAS_RES_STATS) {
+          s0[ni] += v;
+          s1[ni] = fmaf(v, v, s1[ni]);
+        }
         if (EPI == EPI_BIAS_GELU) v = g.gelu_tanh ? gelu_tanh(v) : gelu_erf(v);
         if (EPI == EPI_BIAS_RELU_Q) v = fmaxf(v, 0.f) + qv;          // head.py:94,97
         if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) v = fmaxf(v + rv[e], 0.f);  // head.py:98
@@ -121,6 +126,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
           cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
 #endif
         }
+      }
+    }
+  }
+  if (EPI == EPI_BIAS_RES_STATS) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float a = s0[ni] + __shfl_xor(s0[ni], 32, 64);
+      const float c = s1[ni] + __shfl_xor(s1[ni], 32, 64);
+      if (h == 0) {
+        const int64_t t = t_w0 + ni * 32 + i;
+        atomicAdd(g.st_sum + t, a);  // N / block height = 2 addends per token: order-independent
+        atomicAdd(g.st_sq + t, c);
       }
     }
   }
@@ -188,7 +205,12 @@ __global__ __launch_bounds__(256, DC_G_OCC) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int64_t t = t_blk + wt * 64 + ni * 32 + i;
-      const float m = g.mean[t], r = g.rstd[t];
+      float m = g.mean[t], r = g.rstd[t];
+      if (g.stats_are_sums) {  // fused statistics: m = sum, r = sum of squares over the K channels
+        m = m / (float)g.K;
+        const float var = fmaxf(r / (float)g.K - m * m, 0.f);
+        r = 1.0f / sqrtf(var + g.ln_eps);
+      }
       rs[ni] = r;
       nm[ni] = -m * r;
     }
@@ -319,7 +341,8 @@ static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered
 template <int EPI, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][NI], float* patch, int n_w0,
                                                   int64_t t_w0, int lane) {
-  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED);
+  constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED) ||
+                       (EPI == EPI_BIAS_RES_STATS);
   const int i = lane & 31, h = lane >> 5;
   const int rr = lane >> 3, c4 = (lane & 7) * 4;  // read-back: row rr (+8 per pass), 4 tokens at column c4
 #pragma unroll
@@ -356,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float x = o[c];
-          if (EPI == EPI_BIAS_RES) x += r4[c];
+          if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS) x += r4[c];
           if (EPI == EPI_BIAS_GELU) x = g.gelu_tanh ? gelu_tanh(x) : gelu_erf(x);
           if (EPI == EPI_BIAS_RELU_Q) x = fmaxf(x, 0.f) + q4[c];       // head.py:94,97
           if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) x = fmaxf(x + r4[c], 0.f);  // head.py:98
@@ -463,7 +486,12 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     nm[ni] = 0.f;
     if (LN) {
       const int64_t t = t_blk + t_w + ni * 32 + i;
-      const float m = g.mean[t], r = g.rstd[t];
+      float m = g.mean[t], r = g.rstd[t];
+      if (g.stats_are_sums) {  // fused statistics: m = sum, r = sum of squares over the K channels
+        m = m / (float)g.K;
+        const float var = fmaxf(r / (float)g.K - m * m, 0.f);
+        r = 1.0f / sqrtf(var + g.ln_eps);
+      }
       rs[ni] = r;
       nm[ni] = -m * r;
     }
@@ -609,7 +637,12 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
       nm[ni] = 0.f;
       if (LN) {
         const int64_t t = t_blk + t_w + ni * 32 + i;
-        const float m = g.mean[t], r = g.rstd[t];
+        float m = g.mean[t], r = g.rstd[t];
+        if (g.stats_are_sums) {
+          m = m / (float)g.K;
+          const float var = fmaxf(r / (float)g.K - m * m, 0.f);
+          r = 1.0f / sqrtf(var + g.ln_eps);
+        }
         rs[ni] = r;
         nm[ni] = -m * r;
       }
@@ -682,7 +715,7 @@ static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
     // persist: 0 = one tile per workgroup, 1 = persistent for K <= 256, 2 = persistent for every GEMM,
     // 3 = measured best per epilogue: persistent (direct epilogue) except for the GELU and fused-head epilogues
     if ((persist == 1 && g.K <= 256) || persist == 2 ||
-        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED)) {
+        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) || EPI == EPI_BIAS_RES_STATS) {
       unsigned gp = 256u * DC_H_OCC;  // one wave of workgroups: occupancy x 256 CUs (multiple of 8)
       if (gp > grid6) gp = (grid6 + 7u) & ~7u;
       hipLaunchKernelGGL((gemm6p_kernel<EPI, LN>), dim3(gp), dim3(64 * H_NW), 0, st, g);
@@ -712,6 +745,9 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln) {
       case EPI_HEAD2_FUSED:
         DC_REQUIRE(g.Wp && g.w3 && g.part, "EPI_HEAD2_FUSED needs the bf16x6 path, w3 and part");
         return launch_gemm_t<EPI_HEAD2_FUSED, false>(st, g);
+      case EPI_BIAS_RES_STATS:
+        DC_REQUIRE(g.Wp && g.st_sum && g.st_sq, "EPI_BIAS_RES_STATS needs the bf16x6 path and the statistics buffers");
+        return launch_gemm_t<EPI_BIAS_RES_STATS, false>(st, g);
       default: break;
     }
   }
