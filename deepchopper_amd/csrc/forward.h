@@ -63,6 +63,9 @@ struct HyenaArgs {
   int64_t Tp;
   int D;
   int CH;              // channels per workgroup (1, 2 or 4)
+  const unsigned short* kfp;  // hyena3: bf16 filter planes [D][3][8][kfp_nu][8] (reversed, 8 shifted copies)
+  int kfp_nu;          // 16-byte units per (plane, shift) copy
+  int kf_taps;         // taps of the materialised filter (multiple of 1024)
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
@@ -70,6 +73,9 @@ int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (p
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
+int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
+int hyena3_units(int kf_taps);  // 16-byte units per (plane, shift) copy of the bf16 filter planes
+int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp);
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);

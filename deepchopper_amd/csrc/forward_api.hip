@@ -29,6 +29,7 @@ struct LayerDev {
         *fw2 = nullptr, *fb2 = nullptr, *fw3 = nullptr, *freq0 = nullptr, *freq1 = nullptr, *freq2 = nullptr,
         *deltas = nullptr, *fbias = nullptr;
   float* kf = nullptr;  // [D][kf_taps] materialised long filter
+  unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
 };
 
 struct ProfEvent {
@@ -193,8 +194,11 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
       DC_HIP_CHECK(hipStreamSynchronize(st));
       DC_HIP_CHECK(hipFree(L.kf));
       L.kf = nullptr;
+      if (L.kfp) DC_HIP_CHECK(hipFree(L.kfp));
+      L.kfp = nullptr;
     }
     DC_HIP_CHECK(hipMalloc((void**)&L.kf, (size_t)c.d_model * taps * sizeof(float)));
+    DC_HIP_CHECK(hipMalloc((void**)&L.kfp, (size_t)c.d_model * 3 * 8 * hyena3_units((int)taps) * 16));
     FilterArgs f{};
     f.pos_z = L.pos_z;
     f.pos_t = L.pos_t;
@@ -212,6 +216,7 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
     f.out_stride = taps;
     int rc = launch_filter(st, f);
     if (rc) return rc;
+    if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp))) return rc;
   }
   m->kf_taps = taps;
   return DC_OK;
@@ -458,10 +463,16 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.Tp = Tp;
       a.D = D;
       a.CH = CH;
+      a.kfp = L.kfp;
+      a.kfp_nu = hyena3_units((int)m->kf_taps);
+      a.kf_taps = (int)m->kf_taps;
       ProfScope ps(m, st, "hyena");
-      static const bool old_hyena = getenv("DC_HYENA_V1") != nullptr;  // A/B switch, default = hyena2
-      if ((rc = old_hyena ? launch_hyena(st, a, m->n_groups, m->max_P) : launch_hyena2(st, a, m->n_groups, m->max_P)))
-        return rc;
+      // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
+      static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
+      const int hy = hy_env ? hy_env : (m->gemm_mode == 1 ? 3 : 2);
+      rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P)
+                   : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P) : launch_hyena3(st, a, m->n_groups, m->max_P);
+      if (rc) return rc;
     }
     if (sums && (rc = zero_stats())) return rc;
     if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false,
@@ -616,8 +627,10 @@ extern "C" void dc_model_free(dc_model* m) {
   if (!m) return;
   (void)hipDeviceSynchronize();
   for (void* p : m->owned) (void)hipFree(p);
-  for (auto& L : m->layers)
+  for (auto& L : m->layers) {
     if (L.kf) (void)hipFree(L.kf);
+    if (L.kfp) (void)hipFree(L.kfp);
+  }
   for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     if (b->p) (void)hipFree(b->p);
   if (m->pinned) (void)hipHostFree(m->pinned);
@@ -652,6 +665,7 @@ extern "C" int64_t dc_model_device_bytes(const dc_model* m) {
   if (!m) return 0;
   int64_t b = m->weight_bytes;
   b += (int64_t)m->layers.size() * m->cfg.d_model * m->kf_taps * (int64_t)sizeof(float);
+  b += (int64_t)m->layers.size() * m->cfg.d_model * 3 * 8 * hyena3_units((int)m->kf_taps) * 16;
   for (const DevBuf* d : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     b += (int64_t)d->bytes;
   return b;

@@ -1183,6 +1183,261 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   return DC_OK;
 }
 
+// -------------------------------------------------------------------------------------
+// hyena3: the long convolution on bf16 MFMA with the error-free 3-way split (same scheme as gemm6).
+//   Y[read][q'] += sum_q Z[read][q] * T_d[q'][q],  T_d[q'][q] = k'[32 d + q' - q]
+// MFMA 32x32x16: A = data (M = 32 reads of the group, K = input phase q), B = Toeplitz block (N = output
+// phase q'), 2 k-steps per block pair, 6 MFMAs per k-step.
+// B fragment of lane (q', h), k-step s: elements j = 0..7 are k'[i0 - j], i0 = 32 d + q' - 16 s - 8 h: a
+// window whose start depends on the lane.  The filter is therefore stored REVERSED, R[m] = k'[Mx - m], in
+// 8 copies shifted by 0..7 elements, so that every window is one aligned 16-byte unit:
+//   unit(sigma, u)[e] = R[8 u + sigma + e],  sigma = (Mx - q') mod 8 (a per-lane constant),
+//   u = (Mx - sigma - q') / 8 - 4 d + 2 s + h.
+// The three bf16 planes of all copies are precomputed per layer (launch_filter_planes); a workgroup
+// keeps the window of units it needs in LDS (copy stride = 2 mod 16 units -> conflict-free b128 reads).
+// -------------------------------------------------------------------------------------
+constexpr int H3_CS = 146;        // LDS copy stride in 16-byte units (>= 132 needed, = 2 mod 16)
+constexpr int H3_ZROW = 40;       // bf16 per read row of a z plane (80 B: conflict-free b128 reads)
+constexpr int H3_FILT_BYTES = 3 * 8 * H3_CS * 16;        // 56 064
+constexpr int H3_ZBUF_BYTES = 3 * 32 * H3_ZROW * 2;      // 7 680 per buffer
+
+int hyena3_units(int kf_taps) { return kf_taps / 8 + 8; }
+
+__global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restrict__ kf, int D, int kf_taps, int nu,
+                                                            unsigned short* __restrict__ kfp) {
+  // one thread per (channel, shift, unit)
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)D * 8 * nu;
+  if (idx >= total) return;
+  const int u = (int)(idx % nu);
+  const int sg = (int)((idx / nu) % 8);
+  const int c = (int)(idx / ((int64_t)nu * 8));
+  const int Mx = kf_taps + 7;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = Mx - (8 * u + sg + e);
+    x[e] = (i >= 0 && i < kf_taps) ? kf[(int64_t)c * kf_taps + i] : 0.f;
+  }
+  bf16x8 hh, mm, ll;
+  split3(x, hh, mm, ll);
+  bf16x8* out = reinterpret_cast<bf16x8*>(kfp);
+  const int64_t base = (((int64_t)c * 3) * 8 + sg) * nu + u;
+  out[base] = hh;
+  out[base + (int64_t)8 * nu] = mm;
+  out[base + (int64_t)16 * nu] = ll;
+}
+
+int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp) {
+  const int nu = hyena3_units(kf_taps);
+  const int64_t total = (int64_t)D * 8 * nu;
+  hipLaunchKernelGGL(filter_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kf, D, kf_taps, nu,
+                     kfp);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+template <int CB>  // blocks per output chunk: 32 (reads up to 1024 tokens, one filter window) or 16
+__global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_h3[];
+  constexpr int NACC = CB / 4;
+  const int g = blockIdx.x, c = blockIdx.y, oc = blockIdx.z;
+  const int P = a.grp_P[g];
+  if (CB * oc >= P) return;  // block-uniform
+  const int p_out0 = CB * oc;
+  const int p_out_last = (p_out0 + CB - 1 < P - 1) ? p_out0 + CB - 1 : P - 1;
+
+  unsigned char* s_filt = s_h3;                    // [3][8][H3_CS] x 16 B   (aliased by the epilogue patches)
+  unsigned char* s_z = s_h3 + H3_FILT_BYTES;       // 2 x [3][32][H3_ZROW] bf16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+
+  // ---- producer role: thread -> (read zr, steps zq4..zq4+3) ----
+  const int zr = tid >> 3, zq4 = (tid & 7) * 4;
+  int rz = a.grp_reads[g * 32 + zr];
+  const bool z_valid = rz >= 0;
+  if (!z_valid) rz = a.grp_reads[g * 32];
+  const int64_t z_off = a.toff[rz];
+  const int z_nblk = z_valid ? a.nblk[rz] : 0;
+  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + z_off;
+  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + z_off;
+  const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
+              bx1 = a.sb[a.D + c];
+  const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
+              wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
+  auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
+    l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < z_nblk) {
+      const int64_t t = 32 * p + zq4;
+      if (t > 0) {
+        l1 = *reinterpret_cast<const float4*>(ux1 + t - 4);
+        lv = *reinterpret_cast<const float4*>(uv + t - 4);
+      }
+      c1 = *reinterpret_cast<const float4*>(ux1 + t);
+      cv = *reinterpret_cast<const float4*>(uv + t);
+    }
+  };
+  auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
+    float z[4];
+    z[0] = fmaf(wx1_0, l1.z, fmaf(wx1_1, l1.w, fmaf(wx1_2, c1.x, bx1))) * fmaf(wv_0, lv.z, fmaf(wv_1, lv.w, fmaf(wv_2, cv.x, bv)));
+    z[1] = fmaf(wx1_0, l1.w, fmaf(wx1_1, c1.x, fmaf(wx1_2, c1.y, bx1))) * fmaf(wv_0, lv.w, fmaf(wv_1, cv.x, fmaf(wv_2, cv.y, bv)));
+    z[2] = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
+    z[3] = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
+    if (!(p < z_nblk)) z[0] = z[1] = z[2] = z[3] = 0.f;
+    // error-free 3-way split of 4 values -> three 8-byte stores
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hh, mm, ll;
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const f32x2 v = {z[j], z[j + 1]};
+      const bf16x2 hp = __builtin_convertvector(v, bf16x2);
+      const f32x2 r1 = v - __builtin_convertvector(hp, f32x2);
+      const bf16x2 mp = __builtin_convertvector(r1, bf16x2);
+      const f32x2 r2 = r1 - __builtin_convertvector(mp, f32x2);
+      const bf16x2 lp = __builtin_convertvector(r2, bf16x2);
+      hh[j] = hp[0]; hh[j + 1] = hp[1];
+      mm[j] = mp[0]; mm[j + 1] = mp[1];
+      ll[j] = lp[0]; ll[j + 1] = lp[1];
+    }
+    unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (zr * H3_ZROW + zq4) * 2;
+    *reinterpret_cast<bf16x4*>(zb) = hh;
+    *reinterpret_cast<bf16x4*>(zb + 32 * H3_ZROW * 2) = mm;
+    *reinterpret_cast<bf16x4*>(zb + 2 * 32 * H3_ZROW * 2) = ll;
+  };
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int m = 0; m < NACC; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+  // per-lane constants of the B (filter) fragment address
+  const int NT = a.kf_taps, Mx = NT + 7;
+  const int sg = (Mx - r32) & 7;
+  const int u_c = (Mx - sg - r32) >> 3;
+  const bf16x8* gfp = reinterpret_cast<const bf16x8*>(a.kfp) + (int64_t)c * 3 * 8 * a.kfp_nu;
+
+  const int n_ic = oc + 1;  // input chunks 0 .. oc
+  for (int ic = 0; ic < n_ic; ++ic) {
+    const int p_in0 = CB * ic;
+    const int p_in_last = (p_in0 + CB - 1 < p_out_last) ? p_in0 + CB - 1 : p_out_last;
+    // block distances d = p' - p occurring in this (oc, ic) pair
+    const int d_hi = p_out_last - p_in0;
+    const int d_lo = (p_out0 - p_in_last > 0) ? p_out0 - p_in_last : 0;
+    const int u_base = NT / 8 - 4 - 4 * d_hi;
+    const int n_units = 4 * (d_hi - d_lo) + 8;  // <= 132 <= H3_CS
+    __syncthreads();                            // previous window / z tiles no longer in use
+    for (int idx = tid; idx < 24 * n_units; idx += 256) {
+      const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
+      reinterpret_cast<bf16x8*>(s_filt)[cp * H3_CS + j] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+    }
+    {
+      float4 l1, c1, lv, cv;
+      z_load(p_in0, l1, c1, lv, cv);
+      z_store(p_in0, l1, c1, lv, cv);
+    }
+    __syncthreads();
+
+    for (int p = p_in0; p <= p_in_last; ++p) {
+      float4 l1, c1, lv, cv;
+      const bool more = p < p_in_last;
+      if (more) z_load(p + 1, l1, c1, lv, cv);
+
+      // A (data) fragments: z[read r32][16 s + 8 h .. +7] of the three planes
+      const unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (r32 * H3_ZROW + 8 * h) * 2;
+      bf16x8 za[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          za[s][pl] = *reinterpret_cast<const bf16x8*>(zb + pl * (32 * H3_ZROW * 2) + s * 32);
+#pragma unroll
+      for (int m = 0; m < NACC; ++m) {
+        const int pp = p_out0 + wave + 4 * m;  // owned output block (wave-uniform)
+        if (pp >= p && pp <= p_out_last) {
+          const int d = pp - p;
+          const bf16x8* fb = reinterpret_cast<const bf16x8*>(s_filt) + sg * H3_CS + (u_c - 4 * d + h - u_base);
+          bf16x8 fk[2][3];
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
+          f32x16 cacc = acc[m];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][2], fk[s][0], cacc, 0, 0, 0);  // small terms first
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][1], fk[s][1], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][2], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][1], fk[s][0], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][1], cacc, 0, 0, 0);
+            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][0], cacc, 0, 0, 0);
+          }
+          acc[m] = cacc;
+        }
+      }
+      if (more) z_store(p + 1, l1, c1, lv, cv);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C[read][q'] -> patch -> row-wise: y = conv * sf(x0), 16 B per lane ----
+  // (all waves passed the last barrier: the filter window is dead, each wave takes a 32 x 33 patch of it)
+  float* patch = reinterpret_cast<float*>(s_filt) + wave * (32 * 33);
+  const int er = lane >> 1, eh = (lane & 1) * 16;  // read-back: read er, steps eh .. eh+15
+  int re = a.grp_reads[g * 32 + er];
+  const bool e_valid = re >= 0;
+  if (!e_valid) re = a.grp_reads[g * 32];
+  const int64_t e_off = a.toff[re];
+  const int e_nblk = e_valid ? a.nblk[re] : 0;
+  const float* ux0 = a.u + (int64_t)c * a.Tp + e_off;
+  float* yrow = a.y + (int64_t)c * a.Tp + e_off;
+  const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
+#pragma unroll
+  for (int m = 0; m < NACC; ++m) {
+    const int pp = p_out0 + wave + 4 * m;
+    if (pp <= p_out_last) {  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r32] = acc[m][e];
+      if (pp < e_nblk) {
+        const int64_t t0 = 32 * pp + eh;
+        float w[20];
+        load_window20(ux0, t0, t0 > 0, true, w);
+        float o[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float gate = fmaf(wx0_0, w[s + 2], fmaf(wx0_1, w[s + 3], fmaf(wx0_2, w[s + 4], bx0)));
+          o[s] = patch[er * 33 + eh + s] * gate;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(yrow + t0 + 4 * j) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+      }
+    }
+  }
+}
+
+int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
+  DC_REQUIRE(a.kfp && a.kfp_nu == hyena3_units(a.kf_taps), "hyena3 needs the bf16 filter planes");
+  const size_t lds = (size_t)H3_FILT_BYTES + 2 * H3_ZBUF_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (max_P <= 32) {
+    hipLaunchKernelGGL(hyena3_kernel<32>, dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL(hyena3_kernel<16>, dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
+  }
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   DC_REQUIRE(a.D % a.CH == 0, "CH must divide D");
   const size_t lds = (size_t)a.CH * (32 + 32 * (size_t)max_P) * sizeof(float);
