@@ -39,7 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 
 DOMINANT = "gemm_head2"       # head linear2 (1024x1024): 23.5 % of the algorithmic flops, one launch / step
 # HBM (L2-miss) bytes per token of the dominant kernel from the PMC passes committed in
 # profiles/r01_pmc_hbm_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / tokens, gfx950 correction applied.
-PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024}
+PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024}  # refreshed per mode when re-profiled
 
 
 def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct synthetic batches kept in HBM")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6"], default=os.environ.get("DC_GEMM_MODE", "bf16x6"))
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "fp16x3"], default=os.environ.get("DC_GEMM_MODE", "fp16x3"))
     args = ap.parse_args()
 
     import torch
@@ -152,6 +152,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist_max(elapsed, device="cuda")  # the slowest rank defines the job's time
 
+    fp16_overflow = model.net.overflow() if args.gemm_mode == "fp16x3" else 0  # range guard of the fp16 split
     prof = model.net.profile() if not args.no_profile else {}
     model.net.set_profiling(False)
 
@@ -172,7 +173,10 @@ def main():
             if args.gemm_mode == "bf16x6":
                 # fp32-equivalent GEMM executed as 6 bf16 MFMAs per algorithmic multiply-add: the roofline
                 # is the bf16 MFMA peak; `executed_frac` counts the 6x MFMA work actually issued.
-                peak, kern = PEAK_BF16_MFMA_TFLOPS, "gemm6_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024, bf16x6)"
+                peak, kern = PEAK_BF16_MFMA_TFLOPS, "gemm6_kernel<EPI_HEAD2_FUSED,false,0> (head linear2+3, K=N=1024, bf16x6)"
+            elif args.gemm_mode == "fp16x3":
+                # 2-way fp16 split, 3 fp16 MFMAs per algorithmic multiply-add (fp16 MFMA peak = bf16 peak)
+                peak, kern = PEAK_BF16_MFMA_TFLOPS, "gemm6_kernel<EPI_HEAD2_FUSED,false,1> (head linear2+3, K=N=1024, fp16x3)"
             else:
                 peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024, fp32 MFMA)"
             roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -184,8 +188,10 @@ def main():
                 roof["traffic"] = int(PMC_TRAFFIC_BYTES_PER_TOKEN[args.gemm_mode] * padded)
                 roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 roof["algorithmic_hbm_bytes_per_launch"] = int(padded * (2 * 1024 * 4 + 16))  # B operand + residual, fp32
-            if args.gemm_mode == "bf16x6":
-                roof["executed_frac"] = round(6 * ach / peak, 4)
+            if args.gemm_mode in ("bf16x6", "fp16x3"):
+                mult = 6 if args.gemm_mode == "bf16x6" else 3
+                roof["mfma_per_algorithmic_fma"] = mult
+                roof["executed_frac"] = round(mult * ach / peak, 4)
                 roof["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         if "forward" in stages:
             stages["forward"]["tflops_all_gemm_flops"] = round(
@@ -232,7 +238,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.gemm_mode == "f32" else "f32 (GEMMs as error-free 3xbf16 split on bf16 MFMA, fp32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (GEMMs as error-free 3xbf16 split on bf16 MFMA, fp32 accumulate)",
+                      "fp16x3": "f32 (GEMMs as 2xfp16 split on fp16 MFMA, 22-bit products, fp32 accumulate, range-guarded)"}[args.gemm_mode],
             "data": "synthetic",
             "config": {"workload": f"configs[1]: synthetic {L}-bp reads, 1xMI355X batches of {B} reads "
                                    f"(tokenise -> HyenaDNA forward -> argmax/smooth/intervals), synthetic weights",
@@ -241,6 +248,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": f1,
+            "fp16_overflow_events": fp16_overflow,
             "stages": stages,
         }))
     if world > 1:

@@ -19,7 +19,11 @@ enum GemmEpilogue {
 
 struct GemmArgs {
   const float* Wt;    // [K][N]  pre-transposed (and LayerNorm-gamma folded) weights (fp32 MFMA path)
-  const unsigned short* Wp;  // [3][K/8][N][8] bf16 planes h|m|l of Wt (bf16x6 path) or nullptr
+  const unsigned short* Wp;  // split planes of Wt, [NP][K/8][N][8] 16-bit: bf16 h|m|l (split_mode 0) or fp16 h|l of
+                             // Wt * w_scale (split_mode 1); nullptr selects the fp32-MFMA kernel
+  int split_mode;            // 0 = bf16x6, 1 = fp16x3
+  float w_inv_scale;         // fp16x3: 1 / w_scale (a power of two), applied to the accumulator in the epilogue
+  int* overflow;             // fp16x3: device counter bumped when an activation is outside the fp16 range
   const float* X;     // [K][Tp]
   float* C;           // [N][Tp]
   const float* bias;  // [N]     (LayerNorm-beta folded)

@@ -24,6 +24,8 @@ struct LayerDev {
   float *Wt_fc1 = nullptr, *b_fc1 = nullptr;  // [D][DI], [DI]  (norm2 folded)
   float *Wt_fc2 = nullptr, *b_fc2 = nullptr;  // [DI][D], [D]
   unsigned short *Wp_in = nullptr, *Wp_out = nullptr, *Wp_fc1 = nullptr, *Wp_fc2 = nullptr;  // bf16 planes
+  unsigned short *Wq_in = nullptr, *Wq_out = nullptr, *Wq_fc1 = nullptr, *Wq_fc2 = nullptr;  // fp16 planes (scaled)
+  float is_in = 1.f, is_out = 1.f, is_fc1 = 1.f, is_fc2 = 1.f;                              // 1 / weight scale
   // implicit filter parameters (device copies, checkpoint layout)
   float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
         *fw2 = nullptr, *fb2 = nullptr, *fw3 = nullptr, *freq0 = nullptr, *freq1 = nullptr, *freq2 = nullptr,
@@ -46,8 +48,11 @@ struct dc_model {
   std::vector<LayerDev> layers;
   float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
   unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
+  unsigned short *Wq_l1 = nullptr, *Wq_l2 = nullptr;
+  float is_l1 = 1.f, is_l2 = 1.f;
+  int* d_overflow = nullptr;  // fp16x3 range guard (device counter)
   float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
-  int gemm_mode = 1;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split on bf16 MFMA, fp32-equivalent)
+  int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
@@ -125,6 +130,66 @@ int upload_planes(dc_model* m, const std::vector<float>& Wt, int K, int N, unsig
       pl[idx] = hh;
       pl[plane + idx] = mm;
       pl[2 * plane + idx] = ll;
+    }
+  void* p = nullptr;
+  int rc = dev_alloc(m, pl.size() * sizeof(unsigned short), &p);
+  if (rc) return rc;
+  DC_HIP_CHECK(hipMemcpy(p, pl.data(), pl.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  *out = (unsigned short*)p;
+  return DC_OK;
+}
+
+// fp16 conversion on the host (round to nearest even, subnormals kept)
+inline unsigned short f32_to_f16_rne(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7FFFFFFFu;
+  if (x >= 0x47800000u) return (unsigned short)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+  if (x < 0x38800000u) {  // below 2^-14: half subnormal, value = r * 2^-24
+    float fa;
+    memcpy(&fa, &x, 4);
+    const uint32_t r = (uint32_t)lrintf(fa * 16777216.0f);
+    return (unsigned short)(sign | r);
+  }
+  const uint32_t mant = x & 0x7FFFFFu, e = (x >> 23) - 127 + 15;
+  uint32_t hbits = (e << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (hbits & 1u))) ++hbits;
+  return (unsigned short)(sign | hbits);
+}
+inline float f16_to_f32(unsigned short hb) {
+  const uint32_t e = (hb >> 10) & 31u, mant = hb & 0x3FFu;
+  float v;
+  if (e == 0) v = (float)mant * 5.9604644775390625e-8f;  // 2^-24
+  else if (e == 31) v = mant ? NAN : INFINITY;
+  else v = std::ldexp((float)(mant | 0x400u), (int)e - 25);
+  return (hb & 0x8000u) ? -v : v;
+}
+
+// fp16x3 planes: Wt * scale = h + l with h = fp16(Wt * scale), l = fp16(Wt * scale - h); scale is the power of
+// two that puts max|Wt| in [1024, 2048).  Layout [2][K/8][N][8].
+int upload_planes_f16(dc_model* m, const std::vector<float>& Wt, int K, int N, unsigned short** out,
+                      float* inv_scale) {
+  float mx = 0.f;
+  for (float v : Wt) mx = std::max(mx, std::fabs(v));
+  int e = 0;
+  if (mx > 0.f) {
+    (void)std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+    e = 11 - e;                // mx * 2^e in [1024, 2048)
+  }
+  const float scale = std::ldexp(1.0f, e);
+  *inv_scale = std::ldexp(1.0f, -e);
+  std::vector<unsigned short> pl((size_t)2 * K * N);
+  const size_t plane = (size_t)K * N;
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) {
+      const float x = Wt[(size_t)k * N + n] * scale;  // exact (power of two)
+      const unsigned short hh = f32_to_f16_rne(x);
+      const unsigned short ll = f32_to_f16_rne(x - f16_to_f32(hh));
+      const size_t idx = ((size_t)(k >> 3) * N + n) * 8 + (k & 7);
+      pl[idx] = hh;
+      pl[plane + idx] = ll;
     }
   void* p = nullptr;
   int rc = dev_alloc(m, pl.size() * sizeof(unsigned short), &p);
@@ -264,12 +329,22 @@ struct ProfScope {
   }
 };
 
-int run_gemm(dc_model* m, hipStream_t st, const char* name, const float* Wt, const unsigned short* Wp,
-             const float* X, float* C, const float* bias, const float* R, const float* q, bool ln, int epi, int K,
-             int N, bool stats_are_sums = false) {
+struct WRef {  // the three device forms of one weight matrix
+  const float* Wt;
+  const unsigned short* Wp;  // bf16x6 planes
+  const unsigned short* Wq;  // fp16x3 planes
+  float inv_scale;           // fp16x3: 1 / weight scale
+};
+
+int run_gemm(dc_model* m, hipStream_t st, const char* name, const WRef& w, const float* X, float* C,
+             const float* bias, const float* R, const float* q, bool ln, int epi, int K, int N,
+             bool stats_are_sums = false) {
   GemmArgs g{};
-  g.Wt = Wt;
-  g.Wp = m->gemm_mode == 1 ? Wp : nullptr;
+  g.Wt = w.Wt;
+  g.Wp = m->gemm_mode == 1 ? w.Wp : (m->gemm_mode == 2 ? w.Wq : nullptr);
+  g.split_mode = m->gemm_mode == 2 ? 1 : 0;
+  g.w_inv_scale = m->gemm_mode == 2 ? w.inv_scale : 1.0f;
+  g.overflow = m->d_overflow;
   g.X = X;
   g.C = C;
   g.bias = bias;
@@ -416,7 +491,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   static const bool no_fused_stats = getenv("DC_NO_FUSED_STATS") != nullptr;  // A/B switch
   // bf16x6 mode with the layer-0 table: every LayerNorm input is produced by an out_proj / fc2 GEMM whose
   // epilogue also accumulates the per-token sum and sum of squares -> no separate statistics pass
-  const bool fused_stats = !no_fused_stats && m->gemm_mode == 1;
+  const bool fused_stats = !no_fused_stats && m->gemm_mode >= 1;
   static const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
   const bool l0_table = !no_l0_table && m->u_table0 != nullptr;
   {
@@ -439,7 +514,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         ProfScope ps(m, st, "ln_stats");
         if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
       }
-      if ((rc = run_gemm(m, st, "gemm_inproj", L.Wt_in, L.Wp_in, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D,
+      if ((rc = run_gemm(m, st, "gemm_inproj", WRef{L.Wt_in, L.Wp_in, L.Wq_in, L.is_in}, x, u, L.b_in, nullptr, nullptr, true, EPI_BIAS, D,
                          3 * D, sums)))
         return rc;
     }
@@ -469,24 +544,24 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       ProfScope ps(m, st, "hyena");
       // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
       static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
-      const int hy = hy_env ? hy_env : (m->gemm_mode == 1 ? 3 : 2);
+      const int hy = hy_env ? hy_env : (m->gemm_mode >= 1 ? 3 : 2);
       rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P)
                    : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P) : launch_hyena3(st, a, m->n_groups, m->max_P);
       if (rc) return rc;
     }
     if (sums && (rc = zero_stats())) return rc;
-    if ((rc = run_gemm(m, st, "gemm_outproj", L.Wt_out, L.Wp_out, y, x, L.b_out, x, nullptr, false,
+    if ((rc = run_gemm(m, st, "gemm_outproj", WRef{L.Wt_out, L.Wp_out, L.Wq_out, L.is_out}, y, x, L.b_out, x, nullptr, false,
                        sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, D, D)))
       return rc;
     if (!sums) {
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_fc1", L.Wt_fc1, L.Wp_fc1, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D,
+    if ((rc = run_gemm(m, st, "gemm_fc1", WRef{L.Wt_fc1, L.Wp_fc1, L.Wq_fc1, L.is_fc1}, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D,
                        DI, sums)))
       return rc;
     if (sums && (rc = zero_stats())) return rc;
-    if ((rc = run_gemm(m, st, "gemm_fc2", L.Wt_fc2, L.Wp_fc2, hm, x, L.b_fc2, x, nullptr, false,
+    if ((rc = run_gemm(m, st, "gemm_fc2", WRef{L.Wt_fc2, L.Wp_fc2, L.Wq_fc2, L.is_fc2}, hm, x, L.b_fc2, x, nullptr, false,
                        sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, DI, D)))
       return rc;
   }
@@ -495,13 +570,13 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
     ProfScope ps(m, st, "ln_stats");
     if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
   }
-  if ((rc = run_gemm(m, st, "gemm_head1", m->Wt_l1, m->Wp_l1, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
+  if ((rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
                      head_sums)))
     return rc;
   static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
-  if (m->gemm_mode == 1 && !no_head_fuse) {
+  if (m->gemm_mode >= 1 && !no_head_fuse) {
     // linear2 + residual + ReLU + linear3 in one kernel: the 1024-wide activation never reaches HBM
-    if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
+    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
                        H)))
       return rc;
     ProfScope ps(m, st, "head_out");
@@ -509,7 +584,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
                                  m->d_src_base, m->d_ntok, d_logits)))
       return rc;
   } else {
-    if ((rc = run_gemm(m, st, "gemm_head2", m->Wt_l2, m->Wp_l2, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
+    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
                        H, H)))
       return rc;
     ProfScope ps(m, st, "head_out");
@@ -540,9 +615,17 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   }
   dc_model* m = new dc_model();
   m->cfg = *cfg;
-  if (const char* e = getenv("DC_GEMM_MODE")) m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : 1;
+  if (const char* e = getenv("DC_GEMM_MODE"))
+    m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : ((strcmp(e, "fp16x3") == 0 || strcmp(e, "2") == 0) ? 2 : 1);
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
+  {
+    void* p = nullptr;
+    int rc0 = dev_alloc(m, sizeof(int), &p);
+    if (rc0) return rc0;
+    m->d_overflow = (int*)p;
+    DC_HIP_CHECK(hipMemset(p, 0, sizeof(int)));
+  }
   const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;
   int rc;
 #define UP(expr)        \
@@ -559,6 +642,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     fold_transpose(lw.in_proj_w, lw.in_proj_b, lw.norm1_w, lw.norm1_b, 3 * D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_in));
     UP(upload_planes(m, Wt, D, 3 * D, &L.Wp_in));
+    UP(upload_planes_f16(m, Wt, D, 3 * D, &L.Wq_in, &L.is_in));
     if (li == 0) {
       // u0[v][n] = b'[n] + sum_k Wt[k][n] * (emb[v][k] - mean_v) * rstd_v   (gamma / beta already folded), fp64
       std::vector<float> tab((size_t)cfg->vocab * 3 * D);
@@ -584,14 +668,17 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     fold_transpose(lw.out_proj_w, lw.out_proj_b, nullptr, nullptr, D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_out));
     UP(upload_planes(m, Wt, D, D, &L.Wp_out));
+    UP(upload_planes_f16(m, Wt, D, D, &L.Wq_out, &L.is_out));
     UP(upload(m, bo, &L.b_out));
     fold_transpose(lw.fc1_w, lw.fc1_b, lw.norm2_w, lw.norm2_b, DI, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_fc1));
     UP(upload_planes(m, Wt, D, DI, &L.Wp_fc1));
+    UP(upload_planes_f16(m, Wt, D, DI, &L.Wq_fc1, &L.is_fc1));
     UP(upload(m, bo, &L.b_fc1));
     fold_transpose(lw.fc2_w, lw.fc2_b, nullptr, nullptr, D, DI, Wt, bo);
     UP(upload(m, Wt, &L.Wt_fc2));
     UP(upload_planes(m, Wt, DI, D, &L.Wp_fc2));
+    UP(upload_planes_f16(m, Wt, DI, D, &L.Wq_fc2, &L.is_fc2));
     UP(upload(m, bo, &L.b_fc2));
     UP(upload_raw(m, lw.pos_z, (size_t)cfg->max_seq_len * emb, &L.pos_z));
     UP(upload_raw(m, lw.pos_t, (size_t)cfg->max_seq_len, &L.pos_t));
@@ -611,10 +698,12 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   fold_transpose(w->head_w1, w->head_b1, w->ln_f_w, w->ln_f_b, H, D, Wt, bo);
   UP(upload(m, Wt, &m->Wt_l1));
   UP(upload_planes(m, Wt, D, H, &m->Wp_l1));
+  UP(upload_planes_f16(m, Wt, D, H, &m->Wq_l1, &m->is_l1));
   UP(upload(m, bo, &m->b_l1));
   fold_transpose(w->head_w2, w->head_b2, nullptr, nullptr, H, H, Wt, bo);
   UP(upload(m, Wt, &m->Wt_l2));
   UP(upload_planes(m, Wt, H, H, &m->Wp_l2));
+  UP(upload_planes_f16(m, Wt, H, H, &m->Wq_l2, &m->is_l2));
   UP(upload(m, bo, &m->b_l2));
   UP(upload_raw(m, w->head_w3, (size_t)cfg->num_class * H, &m->W3));
   UP(upload_raw(m, w->head_b3, cfg->num_class, &m->b3));
@@ -686,8 +775,19 @@ extern "C" int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t
 
 extern "C" int dc_model_set_gemm_mode(dc_model* m, int32_t mode) {
   DC_REQUIRE(m, "null pointer");
-  DC_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+  DC_REQUIRE(mode >= 0 && mode <= 2, "gemm mode must be 0 (fp32 MFMA), 1 (bf16x6) or 2 (fp16x3)");
   m->gemm_mode = mode;
+  return DC_OK;
+}
+
+extern "C" int dc_model_overflow(dc_model* m, void* stream, int32_t* count) {
+  DC_REQUIRE(m && count, "null pointer");
+  hipStream_t st = as_stream(stream);
+  int v = 0;
+  DC_HIP_CHECK(hipMemcpyAsync(&v, m->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  DC_HIP_CHECK(hipStreamSynchronize(st));
+  if (v) DC_HIP_CHECK(hipMemsetAsync(m->d_overflow, 0, sizeof(int), st));
+  *count = v;
   return DC_OK;
 }
 

@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
       for (int e = 0; e < 16; ++e) {
         const float4 b4 = bv[e >> 2];
         const float bias = (e & 3) == 0 ? b4.x : (e & 3) == 1 ? b4.y : (e & 3) == 2 ? b4.z : b4.w;
-        float v = acc[mi][ni][e] + bias;
+        float v = fmaf(acc[mi][ni][e], g.w_inv_scale, bias);  // w_inv_scale = 1 except fp16x3
         if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS) v += rv[e];
         if (EPI == EPI_BIAS_RES_STATS) {
           s0[ni] += v;
@@ -329,9 +329,66 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 constexpr int H_BN = DC_H_BN, H_BT = DC_H_BT, H_NW = DC_H_NW;
 constexpr int H_MI = H_BN / 32;            // accumulator tiles down the channel axis
 constexpr int H_NI = H_BT / (32 * H_NW);   // tiles along the token axis per wave
-constexpr int H_A_BYTES = 3 * H_BK * H_BN * 2;
 constexpr int H_B_BYTES = H_BK * H_BT * 4;
 static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered by the waves");
+
+// ---- split schemes of the bf16x6 / fp16x3 GEMMs -------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+struct SplitMode;
+
+// MODE 0, "bf16x6": x = h + m + l exactly in three bf16 terms (24 bits); six cross products p + q <= 2.
+template <>
+struct SplitMode<0> {
+  typedef bf16x8 vec;
+  static constexpr int NP = 3;
+  static __device__ __forceinline__ bool split(const float (&x)[8], vec (&o)[3]) {
+    split3(x, o[0], o[1], o[2]);
+    return false;  // bf16 has the fp32 exponent range: nothing can overflow
+  }
+  static __device__ __forceinline__ f32x16 mma(const vec (&a)[3], const vec (&b)[3], f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);  // small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// MODE 1, "fp16x3": x = h + l in two fp16 terms (2 x 11 = 22 significant bits while |x| stays in the fp16
+// normal range; below it the absolute resolution is the fp16 subnormal spacing 2^-24, i.e. still 2^-24 of
+// an O(1) operand); three cross products h*h + h*l + l*h, the dropped l*l term is <= 2^-22 relative.
+// Weights are pre-scaled per tensor by a power of two into the fp16 range (undone exactly in the epilogue
+// through the bias/scale); |activation| must stay below 65504 (checked: non-finite halves raise a flag).
+template <>
+struct SplitMode<1> {
+  typedef f16x8 vec;
+  static constexpr int NP = 2;
+  static __device__ __forceinline__ bool split(const float (&x)[8], vec (&o)[2]) {
+    bool ovf = false;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      ovf = ovf || !(fabsf(x[j]) <= 65504.f) || !(fabsf(x[j + 1]) <= 65504.f);  // also catches NaN
+      const f32x2 v = {x[j], x[j + 1]};
+      const f16x2 hp = __builtin_convertvector(v, f16x2);
+      const f32x2 r = v - __builtin_convertvector(hp, f32x2);
+      const f16x2 lp = __builtin_convertvector(r, f16x2);
+      o[0][j] = hp[0]; o[0][j + 1] = hp[1];
+      o[1][j] = lp[0]; o[1][j + 1] = lp[1];
+    }
+    return ovf;
+  }
+  static __device__ __forceinline__ f32x16 mma(const vec (&a)[2], const vec (&b)[2], f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
+    return c;
+  }
+};
 
 // Epilogue through LDS: the MFMA accumulator has the token on the lane and the channel on the
 // register (one 4-byte store per lane and register = 64 narrow store instructions per wave and
@@ -373,7 +430,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
       for (int p4 = 0; p4 < 4; ++p4) {
         const int n = n_w0 + mi * 32 + p4 * 8 + rr;
-        float o[4] = {v[p4].x + bias[p4], v[p4].y + bias[p4], v[p4].z + bias[p4], v[p4].w + bias[p4]};
+        const float wi = g.w_inv_scale;  // 1 except fp16x3
+        float o[4] = {fmaf(v[p4].x, wi, bias[p4]), fmaf(v[p4].y, wi, bias[p4]), fmaf(v[p4].z, wi, bias[p4]),
+                      fmaf(v[p4].w, wi, bias[p4])};
         const float r4[4] = {RES ? rv[p4].x : 0.f, RES ? rv[p4].y : 0.f, RES ? rv[p4].z : 0.f, RES ? rv[p4].w : 0.f};
         const float q4[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
@@ -419,8 +478,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   }
 }
 
-template <int EPI, bool LN>
+template <int EPI, bool LN, int MODE>
 __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
+  typedef SplitMode<MODE> SM;
+  typedef typename SM::vec svec;
+  constexpr int H_A_BYTES = SM::NP * H_BK * H_BN * 2;
   constexpr int BUF = H_A_BYTES + H_B_BYTES;
   constexpr int EPI_BYTES = H_NW * 32 * 32 * 4;
   constexpr int S = DC_H_STAGES;  // LDS ring depth: tiles kt+1 .. kt+S-1 are in flight while tile kt is consumed
@@ -449,7 +511,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
   // one LDS-DMA instruction moves 1 KiB: 64 channels x 8 k of one A plane, or 256 floats of the B tile
   constexpr int A_SEG = H_BN / 64;  // 1 KiB segments per (plane, octet) chunk
-  constexpr int A_INSTR = 3 * H_OPT * A_SEG;
+  constexpr int A_INSTR = SM::NP * H_OPT * A_SEG;
   constexpr int B_INSTR = H_B_BYTES / 1024;
   // LDS-DMA instructions per wave and k-tile, rounded DOWN: waves that issue one more only wait a little
   // longer than needed (waiting for fewer outstanding operations is always safe)
@@ -476,6 +538,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   };
 
   const int nk = g.K / H_BK;  // >= 16 for every GEMM of this model, so the ring always fills
+  bool ovf = false;           // fp16x3: an activation left the fp16 range
 #pragma unroll
   for (int st = 0; st < S - 1; ++st) stage(st, st);
 
@@ -519,11 +582,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     }
 #endif
     const unsigned char* bufp = smem6 + cur * BUF;
-    const bf16x8* pA = reinterpret_cast<const bf16x8*>(bufp);
+    const svec* pA = reinterpret_cast<const svec*>(bufp);
     const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
 #pragma unroll
     for (int s = 0; s < H_BK / 16; ++s) {
-      bf16x8 bh[H_NI], bm[H_NI], bl[H_NI];
+      svec bs[H_NI][SM::NP];
 #pragma unroll
       for (int ni = 0; ni < H_NI; ++ni) {
         float x[8];
@@ -532,23 +595,16 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
           const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
           x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
         }
-        split3(x, bh[ni], bm[ni], bl[ni]);
+        ovf |= SM::split(x, bs[ni]);
       }
 #pragma unroll
       for (int mi = 0; mi < H_MI; ++mi) {
-        bf16x8 af[3];
+        svec af[SM::NP];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
+        for (int pl = 0; pl < SM::NP; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
 #pragma unroll
         for (int ni = 0; ni < H_NI; ++ni) {
-          f32x16 c = acc[mi][ni];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bh[ni], c, 0, 0, 0);  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bm[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bl[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bh[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bm[ni], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bh[ni], c, 0, 0, 0);
-          acc[mi][ni] = c;
+          acc[mi][ni] = SM::mma(af, bs[ni], acc[mi][ni]);
         }
       }
     }
@@ -561,6 +617,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     __syncthreads();
     cur = cur + 1 == S ? 0 : cur + 1;
   }
+  if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(g.overflow, 1);
 #ifdef DC_H_DIRECT_EPI
   gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
 #else
@@ -572,8 +629,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 // and requests the first k-tile of its next tile while the last k-tile of the current one is consumed,
 // so the LDS-DMA stream never drains at tile boundaries (no exposed prologue latency per tile).
 // Tiles are dealt per XCD (n fastest) so the blocks of one XCD work on the same token panels.
-template <int EPI, bool LN>
+template <int EPI, bool LN, int MODE>
 __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs g) {
+  typedef SplitMode<MODE> SM;
+  typedef typename SM::vec svec;
+  constexpr int H_A_BYTES = SM::NP * H_BK * H_BN * 2;
   constexpr int BUF = H_A_BYTES + H_B_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * BUF];
 
@@ -592,7 +652,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
   const int i = lane & 31, h = lane >> 5;
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
   constexpr int A_SEG = H_BN / 64;
-  constexpr int A_INSTR = 3 * H_OPT * A_SEG;
+  constexpr int A_INSTR = SM::NP * H_OPT * A_SEG;
   constexpr int B_INSTR = H_B_BYTES / 1024;
   const int K8 = g.K >> 3;
   const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
@@ -615,6 +675,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
   };
   const int nk = g.K / H_BK;
   if (jb >= x_n) return;  // block-uniform: fewer tiles than blocks on this XCD
+  bool ovf = false;       // fp16x3: an activation left the fp16 range
 
   unsigned loc = jb;
   int n_blk = (int)((x_lo + loc) % n_blocks) * H_BN;
@@ -659,11 +720,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
       if (kt + 1 < nk) stage(cur ^ 1, n_blk, t_blk, kt + 1);
       else if (has_next) stage(cur ^ 1, n_next, t_next, 0);  // first k-tile of the next output tile
       const unsigned char* bufp = smem6 + cur * BUF;
-      const bf16x8* pA = reinterpret_cast<const bf16x8*>(bufp);
+      const svec* pA = reinterpret_cast<const svec*>(bufp);
       const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
 #pragma unroll
       for (int s = 0; s < H_BK / 16; ++s) {
-        bf16x8 bh[H_NI], bm[H_NI], bl[H_NI];
+        svec bs[H_NI][SM::NP];
 #pragma unroll
         for (int ni = 0; ni < H_NI; ++ni) {
           float x[8];
@@ -672,23 +733,16 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
             const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
             x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
           }
-          split3(x, bh[ni], bm[ni], bl[ni]);
+          ovf |= SM::split(x, bs[ni]);
         }
 #pragma unroll
         for (int mi = 0; mi < H_MI; ++mi) {
-          bf16x8 af[3];
+          svec af[SM::NP];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
+          for (int pl = 0; pl < SM::NP; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
 #pragma unroll
           for (int ni = 0; ni < H_NI; ++ni) {
-            f32x16 c = acc[mi][ni];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bh[ni], c, 0, 0, 0);  // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bm[ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bl[ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bh[ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bm[ni], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bh[ni], c, 0, 0, 0);
-            acc[mi][ni] = c;
+            acc[mi][ni] = SM::mma(af, bs[ni], acc[mi][ni]);
           }
         }
       }
@@ -703,6 +757,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
     n_blk = n_next;
     t_blk = t_next;
   }
+  if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(g.overflow, 1);
 }
 
 template <int EPI, bool LN>
@@ -718,9 +773,14 @@ static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
         (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) || EPI == EPI_BIAS_RES_STATS) {
       unsigned gp = 256u * DC_H_OCC;  // one wave of workgroups: occupancy x 256 CUs (multiple of 8)
       if (gp > grid6) gp = (grid6 + 7u) & ~7u;
-      hipLaunchKernelGGL((gemm6p_kernel<EPI, LN>), dim3(gp), dim3(64 * H_NW), 0, st, g);
-    } else
-      hipLaunchKernelGGL((gemm6_kernel<EPI, LN>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
+      if (g.split_mode == 1)
+        hipLaunchKernelGGL((gemm6p_kernel<EPI, LN, 1>), dim3(gp), dim3(64 * H_NW), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm6p_kernel<EPI, LN, 0>), dim3(gp), dim3(64 * H_NW), 0, st, g);
+    } else if (g.split_mode == 1)
+      hipLaunchKernelGGL((gemm6_kernel<EPI, LN, 1>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm6_kernel<EPI, LN, 0>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
   } else
     hipLaunchKernelGGL((gemm_kernel<EPI, LN>), dim3(grid), dim3(256), 0, st, g);
   DC_LAUNCH_CHECK();

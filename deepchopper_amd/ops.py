@@ -235,6 +235,10 @@ class HipModel:
         handle = C.c_void_p()
         _lib.check(_lib.lib().dc_model_create(C.byref(c), C.byref(w), C.byref(handle)))
         self._h = handle
+        import os as _os
+
+        self.gemm_mode = {"f32": "f32", "0": "f32", "bf16x6": "bf16x6", "1": "bf16x6"}.get(
+            _os.environ.get("DC_GEMM_MODE", ""), "fp16x3")
         del keep
 
     def close(self):
@@ -281,7 +285,15 @@ class HipModel:
 
     def set_gemm_mode(self, mode: str):
         """"f32": fp32-input MFMA; "bf16x6": error-free 3-way bf16 split on bf16 MFMA (fp32-equivalent)."""
-        _lib.check(_lib.lib().dc_model_set_gemm_mode(self._h, {"f32": 0, "bf16x6": 1}[mode]))
+        _lib.check(_lib.lib().dc_model_set_gemm_mode(self._h, {"f32": 0, "bf16x6": 1, "fp16x3": 2}[mode]))
+        self.gemm_mode = mode
+
+    def overflow(self) -> int:
+        """fp16x3 range guard: workgroups that met an activation outside the fp16 range since the last call
+        (synchronises the stream, clears the counter)."""
+        n = C.c_int32()
+        _lib.check(_lib.lib().dc_model_overflow(self._h, _stream(), C.byref(n)))
+        return int(n.value)
 
     def set_profiling(self, on: bool):
         _lib.check(_lib.lib().dc_model_set_profiling(self._h, int(on)))

@@ -89,9 +89,18 @@ class PredictPipeline:
         sb, offs = ops.pack_reads(seqs)
         qb, _ = ops.pack_reads(quals)
         lens = np.diff(offs)
-        res = self.run_device_batch(ops.to_device(sb), ops.to_device(qb), ops.to_device(offs), lens,
-                                    reference_padding=reference_padding)
+        d_seq, d_qual, d_offs = ops.to_device(sb), ops.to_device(qb), ops.to_device(offs)
+        res = self.run_device_batch(d_seq, d_qual, d_offs, lens, reference_padding=reference_padding)
         torch.cuda.synchronize()
+        net = self.model.net
+        if net.gemm_mode == "fp16x3" and net.overflow() > 0:
+            # an activation left the fp16 range: redo the batch with the bf16 split (fp32 exponent range)
+            net.set_gemm_mode("bf16x6")
+            try:
+                res = self.run_device_batch(d_seq, d_qual, d_offs, lens, reference_padding=reference_padding)
+                torch.cuda.synchronize()
+            finally:
+                net.set_gemm_mode("fp16x3")
         check_read_status(res["tok"]["status"].cpu().numpy(), ids)
         sm = res["smooth"]
         o = sm["offsets"].cpu().numpy()

@@ -241,8 +241,17 @@ int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t seq_len, f
  * chain).  1 = "bf16x6": every fp32 operand is split error-free into three bf16 terms
  * (x = h + m + l, 24 significant bits) and the six leading cross products run on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- fp32-equivalent accuracy (dropped terms
- * <= 2^-24 relative) at 6/16 of the fp32-MFMA cost.  Default: 1; $DC_GEMM_MODE = "f32" selects 0. */
+ * <= 2^-24 relative) at 6/16 of the fp32-MFMA cost.  2 = "fp16x3": x = h + l in two fp16 terms (22 bits),
+ * three cross products on v_mfma_f32_32x32x16_f16, weights pre-scaled by a power of two per tensor; guarded by
+ * dc_model_overflow.  Default: 2; $DC_GEMM_MODE = "f32" | "bf16x6" | "fp16x3". */
 int dc_model_set_gemm_mode(dc_model* m, int32_t mode);
+
+/* fp16x3 range guard.  Mode 2 of dc_model_set_gemm_mode ("fp16x3") splits operands into two fp16 terms
+ * (22 significant bits, three MFMAs); an activation whose magnitude exceeds 65504 cannot be represented
+ * and bumps a device counter.  Synchronises `stream`, returns the number of workgroups that saw such a
+ * value since the last call and clears the counter; callers re-run the batch in mode 1 when it is non-zero
+ * (deepchopper_amd/predict.py does). */
+int dc_model_overflow(dc_model* m, void* stream, int32_t* count);
 
 /* Per-stage device timing with HIP events recorded on the stream the kernels are launched on.
  * While enabled, every kernel launch of dc_forward / dc_forward_ragged is bracketed by an event

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ATOL = 2e-4
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16x6"])
+@pytest.fixture(scope="module", params=["f32", "bf16x6", "fp16x3"])
 def env(hip_lib, request):
     import torch
 
@@ -176,12 +176,12 @@ def test_gemm_modes_error_vs_float64(hip_lib):
     ref64 = fr.forward(sd, ids, q, dtype=torch.float64).numpy()
     ref32 = fr.forward(sd, ids, q).numpy()
     errs = {"oracle_f32": np.abs(ref32 - ref64).max()}
-    for mode in ("f32", "bf16x6"):
+    for mode in ("f32", "bf16x6", "fp16x3"):
         model.set_gemm_mode(mode)
         out = model.forward(ops.to_device(ids), ops.to_device(q)).cpu().numpy()
         errs[mode] = np.abs(out - ref64).max()
     print("max |logit - float64 oracle|:", {k: float(v) for k, v in errs.items()})
-    assert errs["f32"] < 1e-4 and errs["bf16x6"] < 1e-4
+    assert errs["f32"] < 1e-4 and errs["bf16x6"] < 1e-4 and errs["fp16x3"] < 2e-4
     assert errs["bf16x6"] < 4 * max(errs["f32"], errs["oracle_f32"]) + 1e-6
 
 
@@ -224,3 +224,32 @@ def test_forward_ragged_mixed_lengths_config4(env):
         n = int(lens[b])
         ref = fr.forward(sd, ids[b: b + 1, stride - n:].astype(np.int64), q[b: b + 1, stride - n:]).numpy()[0]
         _check(out[b, stride - n:], ref)
+
+
+def test_fp16x3_range_guard_and_fallback(hip_lib):
+    """An activation beyond the fp16 range must not silently corrupt the fp16x3 path: the kernels raise
+    the overflow counter and the pipeline redoes the batch with the bf16 split."""
+    import torch
+
+    from deepchopper_amd import ops, synth
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+    from deepchopper_amd.weights import BB, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = synthetic_state_dict(5)
+    sd[BB + "layers.1.mlp.fc1.bias"] = sd[BB + "layers.1.mlp.fc1.bias"] + np.float32(2.0e5)  # gelu(2e5) = 2e5 > 65504
+    model = DeepChopper.from_state_dict(sd)
+    assert model.net.gemm_mode == "fp16x3"
+    rng = np.random.default_rng(1)
+    ids, q = _inputs(rng, 3, 200)
+    model.net.forward(ops.to_device(ids), ops.to_device(q))
+    assert model.net.overflow() > 0 and model.net.overflow() == 0  # raised once, cleared by the read
+    seq, qual, rid = synth.synth_reads_fixed(6, 200, seed=42)
+    pipe = PredictPipeline(model)
+    out, res = pipe.predict_reads(rid, [s.tobytes() for s in seq], [x.tobytes() for x in qual], reference_padding=True)
+    ref = fr.forward(sd, res["tok"]["input_ids"].cpu().numpy().astype(np.int64), res["tok"]["input_quals"].cpu().numpy()).numpy()
+    got = res["logits"].cpu().numpy()
+    assert np.isfinite(got).all() and model.net.gemm_mode == "fp16x3"
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() < 2e-4 * scale
