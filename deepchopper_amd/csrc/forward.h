@@ -70,6 +70,10 @@ struct HyenaArgs {
   const unsigned short* kfp;  // hyena3: bf16 filter planes [D][3][8][kfp_nu][8] (reversed, 8 shifted copies)
   int kfp_nu;          // 16-byte units per (plane, shift) copy
   int kf_taps;         // taps of the materialised filter (multiple of 1024)
+  const unsigned short* kfp_f16;  // fp16x3: 2 fp16 planes of the per-channel scaled filter, same unit layout
+  const float* ch_inv_scale;      // fp16x3: [D] 1 / (power-of-two scale of the channel's filter)
+  int split_mode;                 // 0 = bf16x6, 1 = fp16x3
+  int* overflow;                  // fp16x3 range guard counter
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
@@ -79,7 +83,8 @@ int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int hyena3_units(int kf_taps);  // 16-byte units per (plane, shift) copy of the bf16 filter planes
-int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp);
+int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
+                         unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale);
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);

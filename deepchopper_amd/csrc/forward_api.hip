@@ -32,6 +32,8 @@ struct LayerDev {
         *deltas = nullptr, *fbias = nullptr;
   float* kf = nullptr;  // [D][kf_taps] materialised long filter
   unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
+  unsigned short* kfq = nullptr;  // fp16 planes (2) of the per-channel scaled filter
+  float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
 };
 
 struct ProfEvent {
@@ -260,10 +262,16 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
       DC_HIP_CHECK(hipFree(L.kf));
       L.kf = nullptr;
       if (L.kfp) DC_HIP_CHECK(hipFree(L.kfp));
-      L.kfp = nullptr;
+      if (L.kfq) DC_HIP_CHECK(hipFree(L.kfq));
+      L.kfp = L.kfq = nullptr;
     }
     DC_HIP_CHECK(hipMalloc((void**)&L.kf, (size_t)c.d_model * taps * sizeof(float)));
     DC_HIP_CHECK(hipMalloc((void**)&L.kfp, (size_t)c.d_model * 3 * 8 * hyena3_units((int)taps) * 16));
+    DC_HIP_CHECK(hipMalloc((void**)&L.kfq, (size_t)c.d_model * 2 * 8 * hyena3_units((int)taps) * 16));
+    if (!L.kscale) {
+      DC_HIP_CHECK(hipMalloc((void**)&L.kscale, (size_t)c.d_model * sizeof(float)));
+      DC_HIP_CHECK(hipMalloc((void**)&L.kinv, (size_t)c.d_model * sizeof(float)));
+    }
     FilterArgs f{};
     f.pos_z = L.pos_z;
     f.pos_t = L.pos_t;
@@ -281,7 +289,7 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
     f.out_stride = taps;
     int rc = launch_filter(st, f);
     if (rc) return rc;
-    if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp))) return rc;
+    if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp, L.kfq, L.kscale, L.kinv))) return rc;
   }
   m->kf_taps = taps;
   return DC_OK;
@@ -541,6 +549,10 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.kfp = L.kfp;
       a.kfp_nu = hyena3_units((int)m->kf_taps);
       a.kf_taps = (int)m->kf_taps;
+      a.kfp_f16 = L.kfq;
+      a.ch_inv_scale = L.kinv;
+      a.split_mode = m->gemm_mode == 2 ? 1 : 0;
+      a.overflow = m->d_overflow;
       ProfScope ps(m, st, "hyena");
       // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
       static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
@@ -719,6 +731,9 @@ extern "C" void dc_model_free(dc_model* m) {
   for (auto& L : m->layers) {
     if (L.kf) (void)hipFree(L.kf);
     if (L.kfp) (void)hipFree(L.kfp);
+    if (L.kfq) (void)hipFree(L.kfq);
+    if (L.kscale) (void)hipFree(L.kscale);
+    if (L.kinv) (void)hipFree(L.kinv);
   }
   for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     if (b->p) (void)hipFree(b->p);

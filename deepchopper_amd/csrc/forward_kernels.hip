@@ -1258,13 +1258,16 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
 // -------------------------------------------------------------------------------------
 constexpr int H3_CS = 146;        // LDS copy stride in 16-byte units (>= 132 needed, = 2 mod 16)
 constexpr int H3_ZROW = 40;       // bf16 per read row of a z plane (80 B: conflict-free b128 reads)
-constexpr int H3_FILT_BYTES = 3 * 8 * H3_CS * 16;        // 56 064
-constexpr int H3_ZBUF_BYTES = 3 * 32 * H3_ZROW * 2;      // 7 680 per buffer
+constexpr int h3_filt_bytes(int np) { return np * 8 * H3_CS * 16; }   // 56 064 (bf16x6) / 37 376 (fp16x3)
+constexpr int h3_zbuf_bytes(int np) { return np * 32 * H3_ZROW * 2; }  // per z buffer
 
 int hyena3_units(int kf_taps) { return kf_taps / 8 + 8; }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restrict__ kf, int D, int kf_taps, int nu,
+                                                            const float* __restrict__ ch_scale,
                                                             unsigned short* __restrict__ kfp) {
+  typedef SplitMode<MODE> SM;
   // one thread per (channel, shift, unit)
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)D * 8 * nu;
@@ -1273,32 +1276,67 @@ __global__ __launch_bounds__(256) void filter_planes_kernel(const float* __restr
   const int sg = (int)((idx / nu) % 8);
   const int c = (int)(idx / ((int64_t)nu * 8));
   const int Mx = kf_taps + 7;
+  const float sc = MODE == 1 ? ch_scale[c] : 1.0f;  // fp16x3: power-of-two scale of this channel's filter
   float x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int i = Mx - (8 * u + sg + e);
-    x[e] = (i >= 0 && i < kf_taps) ? kf[(int64_t)c * kf_taps + i] : 0.f;
+    x[e] = (i >= 0 && i < kf_taps) ? kf[(int64_t)c * kf_taps + i] * sc : 0.f;
   }
-  bf16x8 hh, mm, ll;
-  split3(x, hh, mm, ll);
-  bf16x8* out = reinterpret_cast<bf16x8*>(kfp);
-  const int64_t base = (((int64_t)c * 3) * 8 + sg) * nu + u;
-  out[base] = hh;
-  out[base + (int64_t)8 * nu] = mm;
-  out[base + (int64_t)16 * nu] = ll;
+  typename SM::vec pl[SM::NP];
+  (void)SM::split(x, pl);
+  typename SM::vec* out = reinterpret_cast<typename SM::vec*>(kfp);
+  const int64_t base = (((int64_t)c * SM::NP) * 8 + sg) * nu + u;
+#pragma unroll
+  for (int q = 0; q < SM::NP; ++q) out[base + (int64_t)q * 8 * nu] = pl[q];
 }
 
-int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp) {
+// per-channel power-of-two scale that puts max|k'| into [1024, 2048) (fp16x3) and its inverse
+__global__ __launch_bounds__(256) void filter_scale_kernel(const float* __restrict__ kf, int kf_taps,
+                                                           float* __restrict__ ch_scale,
+                                                           float* __restrict__ ch_inv_scale) {
+  __shared__ float s_max[256];
+  const int c = blockIdx.x;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < kf_taps; i += 256) mx = fmaxf(mx, fabsf(kf[(int64_t)c * kf_taps + i]));
+  s_max[threadIdx.x] = mx;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int e = 0;
+    if (s_max[0] > 0.f) {
+      (void)frexpf(s_max[0], &e);
+      e = 11 - e;
+    }
+    ch_scale[c] = ldexpf(1.0f, e);
+    ch_inv_scale[c] = ldexpf(1.0f, -e);
+  }
+}
+
+int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
+                         unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale) {
   const int nu = hyena3_units(kf_taps);
   const int64_t total = (int64_t)D * 8 * nu;
-  hipLaunchKernelGGL(filter_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kf, D, kf_taps, nu,
-                     kfp);
+  hipLaunchKernelGGL(filter_scale_kernel, dim3(D), dim3(256), 0, st, kf, kf_taps, ch_scale, ch_inv_scale);
+  DC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(filter_planes_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kf, D, kf_taps,
+                     nu, ch_scale, kfp_bf16);
+  DC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(filter_planes_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kf, D, kf_taps,
+                     nu, ch_scale, kfp_f16);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
 
-template <int CB>  // blocks per output chunk: 32 (reads up to 1024 tokens, one filter window) or 16
+template <int CB, int MODE>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16
 __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
+  typedef SplitMode<MODE> SM;
+  typedef typename SM::vec svec;
+  constexpr int NP = SM::NP;
+  constexpr int H3_FILT_BYTES = h3_filt_bytes(NP), H3_ZBUF_BYTES = h3_zbuf_bytes(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_h3[];
   constexpr int NACC = CB / 4;
   const int g = blockIdx.x, c = blockIdx.y, oc = blockIdx.z;
@@ -1307,8 +1345,8 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
   const int p_out0 = CB * oc;
   const int p_out_last = (p_out0 + CB - 1 < P - 1) ? p_out0 + CB - 1 : P - 1;
 
-  unsigned char* s_filt = s_h3;                    // [3][8][H3_CS] x 16 B   (aliased by the epilogue patches)
-  unsigned char* s_z = s_h3 + H3_FILT_BYTES;       // 2 x [3][32][H3_ZROW] bf16
+  unsigned char* s_filt = s_h3;                    // [NP][8][H3_CS] x 16 B  (aliased by the epilogue patches)
+  unsigned char* s_z = s_h3 + H3_FILT_BYTES;       // 2 x [NP][32][H3_ZROW] 16-bit
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1339,6 +1377,7 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
       cv = *reinterpret_cast<const float4*>(uv + t);
     }
   };
+  bool ovf = false;  // fp16x3: a z value left the fp16 range
   auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
     float z[4];
     z[0] = fmaf(wx1_0, l1.z, fmaf(wx1_1, l1.w, fmaf(wx1_2, c1.x, bx1))) * fmaf(wv_0, lv.z, fmaf(wv_1, lv.w, fmaf(wv_2, cv.x, bv)));
@@ -1346,25 +1385,18 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
     z[2] = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
     z[3] = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
     if (!(p < z_nblk)) z[0] = z[1] = z[2] = z[3] = 0.f;
-    // error-free 3-way split of 4 values -> three 8-byte stores
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-    bf16x4 hh, mm, ll;
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-      const f32x2 v = {z[j], z[j + 1]};
-      const bf16x2 hp = __builtin_convertvector(v, bf16x2);
-      const f32x2 r1 = v - __builtin_convertvector(hp, f32x2);
-      const bf16x2 mp = __builtin_convertvector(r1, bf16x2);
-      const f32x2 r2 = r1 - __builtin_convertvector(mp, f32x2);
-      const bf16x2 lp = __builtin_convertvector(r2, bf16x2);
-      hh[j] = hp[0]; hh[j + 1] = hp[1];
-      mm[j] = mp[0]; mm[j + 1] = mp[1];
-      ll[j] = lp[0]; ll[j + 1] = lp[1];
-    }
+    // split of 4 values (padded to the 8-wide splitter) -> NP 8-byte stores
+    const float z8[8] = {z[0], z[1], z[2], z[3], 0.f, 0.f, 0.f, 0.f};
+    svec pl8[NP];
+    ovf = ovf || SM::split(z8, pl8);
     unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (zr * H3_ZROW + zq4) * 2;
-    *reinterpret_cast<bf16x4*>(zb) = hh;
-    *reinterpret_cast<bf16x4*>(zb + 32 * H3_ZROW * 2) = mm;
-    *reinterpret_cast<bf16x4*>(zb + 2 * 32 * H3_ZROW * 2) = ll;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      typedef unsigned long long u64;
+      union { svec v; u64 w[2]; } cv;
+      cv.v = pl8[q];
+      *reinterpret_cast<u64*>(zb + q * (32 * H3_ZROW * 2)) = cv.w[0];
+    }
   };
 
   f32x16 acc[NACC];
@@ -1377,7 +1409,7 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
   const int NT = a.kf_taps, Mx = NT + 7;
   const int sg = (Mx - r32) & 7;
   const int u_c = (Mx - sg - r32) >> 3;
-  const bf16x8* gfp = reinterpret_cast<const bf16x8*>(a.kfp) + (int64_t)c * 3 * 8 * a.kfp_nu;
+  const svec* gfp = reinterpret_cast<const svec*>(MODE == 1 ? a.kfp_f16 : a.kfp) + (int64_t)c * NP * 8 * a.kfp_nu;
 
   const int n_ic = oc + 1;  // input chunks 0 .. oc
   for (int ic = 0; ic < n_ic; ++ic) {
@@ -1389,9 +1421,9 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
     const int u_base = NT / 8 - 4 - 4 * d_hi;
     const int n_units = 4 * (d_hi - d_lo) + 8;  // <= 132 <= H3_CS
     __syncthreads();                            // previous window / z tiles no longer in use
-    for (int idx = tid; idx < 24 * n_units; idx += 256) {
+    for (int idx = tid; idx < NP * 8 * n_units; idx += 256) {
       const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
-      reinterpret_cast<bf16x8*>(s_filt)[cp * H3_CS + j] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+      reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
     }
     {
       float4 l1, c1, lv, cv;
@@ -1407,33 +1439,26 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
 
       // A (data) fragments: z[read r32][16 s + 8 h .. +7] of the three planes
       const unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (r32 * H3_ZROW + 8 * h) * 2;
-      bf16x8 za[2][3];
+      svec za[2][NP];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          za[s][pl] = *reinterpret_cast<const bf16x8*>(zb + pl * (32 * H3_ZROW * 2) + s * 32);
+        for (int pl = 0; pl < NP; ++pl)
+          za[s][pl] = *reinterpret_cast<const svec*>(zb + pl * (32 * H3_ZROW * 2) + s * 32);
 #pragma unroll
       for (int m = 0; m < NACC; ++m) {
         const int pp = p_out0 + wave + 4 * m;  // owned output block (wave-uniform)
         if (pp >= p && pp <= p_out_last) {
           const int d = pp - p;
-          const bf16x8* fb = reinterpret_cast<const bf16x8*>(s_filt) + sg * H3_CS + (u_c - 4 * d + h - u_base);
-          bf16x8 fk[2][3];
+          const svec* fb = reinterpret_cast<const svec*>(s_filt) + sg * H3_CS + (u_c - 4 * d + h - u_base);
+          svec fk[2][NP];
 #pragma unroll
           for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
+            for (int pl = 0; pl < NP; ++pl) fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
           f32x16 cacc = acc[m];
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][2], fk[s][0], cacc, 0, 0, 0);  // small terms first
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][1], fk[s][1], cacc, 0, 0, 0);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][2], cacc, 0, 0, 0);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][1], fk[s][0], cacc, 0, 0, 0);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][1], cacc, 0, 0, 0);
-            cacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za[s][0], fk[s][0], cacc, 0, 0, 0);
-          }
+          for (int s = 0; s < 2; ++s) cacc = SM::mma(za[s], fk[s], cacc);
           acc[m] = cacc;
         }
       }
@@ -1454,6 +1479,8 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
   const float* ux0 = a.u + (int64_t)c * a.Tp + e_off;
   float* yrow = a.y + (int64_t)c * a.Tp + e_off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
+  const float inv_sc = MODE == 1 ? a.ch_inv_scale[c] : 1.0f;  // fp16x3: undo the filter's power-of-two scale
+  if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
 #pragma unroll
   for (int m = 0; m < NACC; ++m) {
     const int pp = p_out0 + wave + 4 * m;
@@ -1468,7 +1495,7 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const float gate = fmaf(wx0_0, w[s + 2], fmaf(wx0_1, w[s + 3], fmaf(wx0_2, w[s + 4], bx0)));
-          o[s] = patch[er * 33 + eh + s] * gate;
+          o[s] = patch[er * 33 + eh + s] * inv_sc * gate;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -1478,24 +1505,33 @@ __global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
   }
 }
 
-int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
-  DC_REQUIRE(a.kfp && a.kfp_nu == hyena3_units(a.kf_taps), "hyena3 needs the bf16 filter planes");
-  const size_t lds = (size_t)H3_FILT_BYTES + 2 * H3_ZBUF_BYTES;
+template <int MODE>
+static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
+  const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
   static bool attr_set = false;
   if (!attr_set) {
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32>),
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16>),
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   if (max_P <= 32) {
-    hipLaunchKernelGGL(hyena3_kernel<32>, dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<32, MODE>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
   } else {
-    hipLaunchKernelGGL(hyena3_kernel<16>, dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<16, MODE>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
   }
   DC_LAUNCH_CHECK();
   return DC_OK;
+}
+
+int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
+  DC_REQUIRE(a.kfp && a.kfp_nu == hyena3_units(a.kf_taps), "hyena3 needs the 16-bit filter planes");
+  if (a.split_mode == 1) {
+    DC_REQUIRE(a.kfp_f16 && a.ch_inv_scale && a.overflow, "fp16x3 long convolution needs its planes / scales / guard");
+    return launch_hyena3_t<1>(st, a, n_groups, max_P);
+  }
+  return launch_hyena3_t<0>(st, a, n_groups, max_P);
 }
 
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
