@@ -39,7 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 
 DOMINANT = "gemm_head2"       # head linear2 (1024x1024): 23.5 % of the algorithmic flops, one launch / step
 # HBM (L2-miss) bytes per token of the dominant kernel from the PMC passes committed in
 # profiles/r01_pmc_hbm_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / tokens, gfx950 correction applied.
-PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024}  # refreshed per mode when re-profiled
+PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024, "fp16x3": 12255.0}  # profiles/r01_pmc_hbm_traffic*.json
 
 
 def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
@@ -100,11 +100,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; DC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code
+    # path on a one-GPU box (ranks then share the device)
+    backend = os.environ.get("DC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from deepchopper_amd import ops, synth
     from deepchopper_amd.model import DeepChopper
@@ -150,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = dist_max(elapsed, device="cuda")  # the slowest rank defines the job's time
+    elapsed = dist_max(elapsed, device="cuda" if backend == "nccl" else "cpu")  # the slowest rank defines the job's time
 
     fp16_overflow = model.net.overflow() if args.gemm_mode == "fp16x3" else 0  # range guard of the fp16 split
     prof = model.net.profile() if not args.no_profile else {}
@@ -186,7 +193,8 @@ def main():
             if args.gemm_mode in PMC_TRAFFIC_BYTES_PER_TOKEN:
                 padded = -(-tokens_per_launch // 256) * 256
                 roof["traffic"] = int(PMC_TRAFFIC_BYTES_PER_TOKEN[args.gemm_mode] * padded)
-                roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["traffic_source"] = ("profiles/r01_pmc_hbm_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                                          % ("_fp16x3" if args.gemm_mode == "fp16x3" else ""))
                 roof["algorithmic_hbm_bytes_per_launch"] = int(padded * (2 * 1024 * 4 + 16))  # B operand + residual, fp32
             if args.gemm_mode in ("bf16x6", "fp16x3"):
                 mult = 6 if args.gemm_mode == "bf16x6" else 3
@@ -241,7 +249,7 @@ def main():
             "dtype": {"f32": "f32", "bf16x6": "f32 (GEMMs as error-free 3xbf16 split on bf16 MFMA, fp32 accumulate)",
                       "fp16x3": "f32 (GEMMs as 2xfp16 split on fp16 MFMA, 22-bit products, fp32 accumulate, range-guarded)"}[args.gemm_mode],
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic {L}-bp reads, 1xMI355X batches of {B} reads "
+            "config": {"workload": f"configs[1]: synthetic {L}-bp reads, {world}xMI355X, batches of {B} reads per GPU "
                                    f"(tokenise -> HyenaDNA forward -> argmax/smooth/intervals), synthetic weights",
                        "reads_per_step_per_gpu": B, "read_len": L, "tokens_per_read": L + 1,
                        "parallelism": f"read-sharded x{world}, no collectives"},
