@@ -78,7 +78,8 @@ def _predict(args) -> int:
         ids = [r[0] for r in chunk]
         reads, res = pipe.predict_reads(ids, [r[1] for r in chunk], [r[2] for r in chunk],
                                         reference_padding=not args.native)
-        write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
+        if not args.no_pt:
+            write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
         if tsv:
             for r in reads:
                 tsv.write(f"{r['id']}\t{len(r['prediction'])}\t" + ",".join(f"{s}:{e}" for s, e in r["intervals"]) + "\n")
@@ -104,6 +105,8 @@ def main(argv=None) -> int:
     p.add_argument("--verbose", "-v", action="store_true", help="Enable verbose output")
     p.add_argument("--native", action="store_true", help="zero-padding batches + per-read intervals TSV")
     p.add_argument("--max-tokens", type=int, default=2_000_000, help="token budget per --native batch")
+    p.add_argument("--no-pt", action="store_true", help="skip the 28 B/token .pt wire format (use with --native: "
+                   "labels / intervals only)")
     p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native batch (-b applies to reference batches)")
     c = sub.add_parser("chop", help="DeepChopper: chop the given predictions!")
     c.add_argument("predicts", nargs="+", help="Paths to prediction folders ({out}/0)")
