@@ -7,13 +7,12 @@ reference's `par_iter` (majority vote -> regions -> filter -> complement) is ONE
 """
 from __future__ import annotations
 
-import gzip
 import os
 
 import numpy as np
 
 from . import ops, rs_api
-from .fastq import iter_fastq
+from .fastq import BgzfWriter, iter_fastq
 from .predict import SmoothParams
 
 CHOP_TYPES = ("terminal", "internal", "all")
@@ -71,9 +70,11 @@ def chop_chunk(records, predicts: dict, sp: SmoothParams, chop_type: str = "all"
 
 
 def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_type: str = "all",
-         output_prefix: str | None = None, chunk_size: int = 10000, max_batch_size: int | None = None) -> str:
+         output_prefix: str | None = None, chunk_size: int = 10000, max_batch_size: int | None = None,
+         threads: int = 2) -> str:
     """main() of src/bin/predict.rs:197-384.  Returns the output path
-    `{prefix or fastq stem}.{n_predictions}pd.{n_records}record.chop.fq.gz`."""
+    `{prefix or fastq stem}.{n_predictions}pd.{n_records}record.chop.fq.gz` -- a BGZF stream written by
+    `threads` compression workers, as the reference's bgzf::io::MultithreadedWriter (predict.rs:266-270)."""
     if chop_type not in CHOP_TYPES:
         raise ValueError("Invalid chop type")
     sp = sp or SmoothParams()
@@ -84,13 +85,13 @@ def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_
     tmp = os.path.join(out_dir, f".deepchopper_temp_{os.getpid()}.fq.gz")
     n_out = 0
     try:
-        with gzip.open(tmp, "wb", compresslevel=4) as fh:
+        with BgzfWriter(tmp, threads=threads) as fh:
             chunk = []
 
             def flush():
                 nonlocal n_out
                 for rid, seq, qual in chop_chunk(chunk, predicts, sp, chop_type):
-                    fh.write(b"@" + rid + b"\n" + seq + b"\n+\n" + qual + b"\n")
+                    fh.write_record(rid, seq, qual)
                     n_out += 1
                 chunk.clear()
 

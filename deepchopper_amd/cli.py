@@ -19,8 +19,39 @@ from pathlib import Path
 
 import numpy as np
 
-from .fastq import iter_fastq
-from .sharding import shard_range
+from .fastq import FastqReader, check_compressed_type, shard_byte_range
+
+
+def rank_chunks(path: str, rank: int, world: int, max_reads: int, max_bases: int, max_sample: int | None = None):
+    """This rank's reads as FastqChunks, streamed (never the whole file in memory).
+
+    Uncompressed and BGZF input: one contiguous byte-range shard per rank, so a rank never
+    parses -- or inflates -- another rank's reads.  Plain gzip cannot be entered mid-stream: every rank
+    inflates the file and keeps every world-th chunk (chunk boundaries depend only on the file and the
+    limits, so ranks agree on them).  `max_sample` (the reference's --max-sample: the first N records of
+    the file) also uses the round-robin form because it needs global record numbers."""
+    kind = check_compressed_type(path)
+    if world > 1 and max_sample is None and kind in ("Uncompress", "Bgzip"):
+        with FastqReader(path, byte_range=shard_byte_range(path, rank, world)) as rd:
+            yield from rd.chunks(max_reads, max_bases)
+        return
+    seen = 0
+    with FastqReader(path) as rd:
+        for i, c in enumerate(rd.chunks(max_reads, max_bases)):
+            if max_sample is not None and seen + c.n > max_sample:
+                c = c.head(max_sample - seen)
+            seen += c.n
+            if c.n and i % world == rank:
+                yield c
+            if max_sample is not None and seen >= max_sample:
+                return
+
+
+def limit_batches(it, limit: int | None):
+    for i, x in enumerate(it):
+        if limit is not None and i >= limit:
+            return
+        yield x
 
 
 def _predict(args) -> int:
@@ -53,40 +84,37 @@ def _predict(args) -> int:
     pipe = PredictPipeline(model)
     out_dir = Path(args.output or "predictions")
     per_dev = args.batch_size // world
-    # whole-file record list (ids / offsets) so that ranks can take contiguous shards
-    records = list(iter_fastq(str(data_path), max_records=args.max_sample))
-    if not records:
-        raise ValueError(f"No valid records found in {data_path}")
-    lo, hi = shard_range(len(records), rank, world)
-    mine = records[lo:hi]
-    tsv = None
-    if args.native:
-        os.makedirs(out_dir / "0", exist_ok=True)
-        tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w")
-    n_batches = 0
+    os.makedirs(out_dir / "0", exist_ok=True)
     if args.native:
         # zero-padding batches bounded by a token budget (mixed-length reads, BASELINE config 4)
-        from .batcher import token_budget_batches
-
-        ranges = list(token_budget_batches([len(r[1]) for r in mine], args.max_tokens, args.max_reads))
+        chunks = rank_chunks(str(data_path), rank, world, args.max_reads, args.max_tokens, args.max_sample)
     else:
-        ranges = [(b0, min(b0 + per_dev, len(mine))) for b0 in range(0, len(mine), per_dev)]
-    for b0, b1 in ranges:
-        if args.limit_batches is not None and n_batches >= args.limit_batches:
-            break
-        chunk = mine[b0:b1]
-        ids = [r[0] for r in chunk]
-        reads, res = pipe.predict_reads(ids, [r[1] for r in chunk], [r[2] for r in chunk],
-                                        reference_padding=not args.native)
-        if not args.no_pt:
-            write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
-        if tsv:
-            for r in reads:
-                tsv.write(f"{r['id']}\t{len(r['prediction'])}\t" + ",".join(f"{s}:{e}" for s, e in r["intervals"]) + "\n")
-        n_batches += 1
-    if tsv:
-        tsv.close()
-    logging.info("rank %d wrote %d batches for reads [%d, %d)", rank, n_batches, lo, hi)
+        # reference batches: `per_dev` reads per step on each rank, left-padded to the longest
+        chunks = rank_chunks(str(data_path), rank, world, per_dev, 1 << 30, args.max_sample)
+    n_batches = n_reads = 0
+    if args.native:
+        with open(out_dir / "0" / f"{rank}.intervals.tsv", "w") as tsv:
+            for res in pipe.predict_stream(limit_batches(chunks, args.limit_batches)):
+                iv, niv, lens = res["intervals"], res["n_intervals"], res["lengths"]
+                tsv.write("".join(
+                    f"{name}\t{int(lens[r])}\t" + ",".join(f"{s}:{e}" for s, e in iv[r, : int(niv[r])].tolist()) + "\n"
+                    for r, name in enumerate(res["names"])))
+                if not args.no_pt:
+                    write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res["device"], res["names"])
+                n_batches += 1
+                n_reads += len(res["names"])
+    else:
+        for chunk in limit_batches(chunks, args.limit_batches):
+            recs = list(chunk.records())
+            ids = [r[0] for r in recs]
+            _, res = pipe.predict_reads(ids, [r[1] for r in recs], [r[2] for r in recs], reference_padding=True)
+            if not args.no_pt:
+                write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
+            n_batches += 1
+            n_reads += len(ids)
+    if n_reads == 0 and world == 1:
+        raise ValueError(f"No valid records found in {data_path}")
+    logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
     return 0
 
 
@@ -120,7 +148,7 @@ def main(argv=None) -> int:
     c.add_argument("--output", "-o", default=None, help="Output prefix")
     c.add_argument("--max-batch", type=int, default=None)
     c.add_argument("--chunk-size", type=int, default=10000)
-    c.add_argument("--threads", "-t", type=int, default=2, help="unused: smoothing runs on the GPU")
+    c.add_argument("--threads", "-t", type=int, default=2, help="BGZF compression workers for the output (smoothing itself runs on the GPU)")
     c.add_argument("--verbose", "-v", action="store_true")
     args = ap.parse_args(argv)
     if args.verbose:
@@ -134,7 +162,7 @@ def main(argv=None) -> int:
         sp = SmoothParams(window=args.smooth_window, min_interval=args.min_interval_size,
                           approved=args.approved_intervals, max_process_intervals=args.max_process_intervals,
                           min_read_length_after_chop=args.min_read_length)
-        path = chop(args.predicts, args.fq, sp, args.chop_type, args.output, args.chunk_size, args.max_batch)
+        path = chop(args.predicts, args.fq, sp, args.chop_type, args.output, args.chunk_size, args.max_batch, args.threads)
         print(path)
         return 0
     return _predict(args)

@@ -1,0 +1,623 @@
+// Host-side FASTQ / gzip / BGZF streaming I/O (include/deepchopper_io.h).  No GPU code: the product of
+// this file is the packed (seq, qual, offsets) triple that dc_tokenize_batch consumes, and the BGZF
+// stream the chop driver emits.
+//
+// Reference behaviour restated here (never its code):
+//   check_compressed_type                     src/output/writefq.rs:84-147
+//   create_reader_for_compressed_file         src/output/writefq.rs:148-161
+//   StreamingFastqReader                      src/output/writefq.rs:172-199  (4-line records, noodles)
+//   parse_fastq_file validation               deepchopper/data/only_fq.py:21-85
+//   bgzf::io::MultithreadedWriter usage       src/output/writefq.rs:252-276, src/bin/predict.rs:266-270
+#include "../../include/deepchopper_io.h"
+
+#include <zlib.h>
+
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+constexpr size_t kBlock = 4u << 20;  // decompressed / plain bytes handed from the source thread per block
+
+// ------------------------------------------------------------------------------------------------
+// Source thread: file -> (inflate) -> bounded queue of byte blocks
+// ------------------------------------------------------------------------------------------------
+struct Source {
+  FILE* fp = nullptr;
+  bool compressed = false;
+  int depth = 4;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv_put, cv_get;
+  std::deque<std::vector<uint8_t>> q;
+  bool done = false, cancel = false;
+  std::string err;
+  std::atomic<int64_t> consumed{0};
+  // BGZF byte-range shards: compressed offset the stream starts at / the block boundary that ends the
+  // range; range_end_u = (decompressed bytes emitted up to that boundary) + 1, published once reached
+  int64_t start_off = 0, end_off = INT64_MAX;
+  std::atomic<int64_t> range_end_u{INT64_MAX};
+
+  void push(std::vector<uint8_t>&& b) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_put.wait(lk, [&] { return (int)q.size() < depth || cancel; });
+    if (cancel) return;
+    q.emplace_back(std::move(b));
+    cv_get.notify_one();
+  }
+  void finish(const std::string& e) {
+    std::lock_guard<std::mutex> lk(mu);
+    err = e;
+    done = true;
+    cv_get.notify_all();
+  }
+  bool cancelled() {
+    std::lock_guard<std::mutex> lk(mu);
+    return cancel;
+  }
+  // returns false at end of stream (err set on failure)
+  bool pop(std::vector<uint8_t>& out, std::string& e) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_get.wait(lk, [&] { return !q.empty() || done; });
+    if (!q.empty()) {
+      out = std::move(q.front());
+      q.pop_front();
+      cv_put.notify_one();
+      return true;
+    }
+    e = err;
+    return false;
+  }
+
+  void run_plain() {
+    for (;;) {
+      if (cancelled()) break;
+      std::vector<uint8_t> b(kBlock);
+      size_t n = fread(b.data(), 1, b.size(), fp);
+      if (n == 0) {
+        if (ferror(fp)) return finish("read error");
+        break;
+      }
+      consumed += (int64_t)n;
+      b.resize(n);
+      push(std::move(b));
+    }
+    finish("");
+  }
+
+  void run_gzip() {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) return finish("inflateInit2 failed");
+    std::vector<uint8_t> in(1u << 20);
+    std::vector<uint8_t> out(kBlock);
+    size_t have = 0;
+    int64_t pushed = 0, fed = 0;  // decompressed bytes already queued / compressed bytes read from the file
+    bool member_open = false;  // inside a gzip member
+    bool eof = false;
+    std::string e;
+    for (;;) {
+      if (cancelled()) break;
+      if (zs.avail_in == 0 && !eof) {
+        size_t n = fread(in.data(), 1, in.size(), fp);
+        if (n == 0) {
+          if (ferror(fp)) { e = "read error"; break; }
+          eof = true;
+        }
+        consumed += (int64_t)n;
+        fed += (int64_t)n;
+        zs.next_in = in.data();
+        zs.avail_in = (uInt)n;
+      }
+      if (zs.avail_in == 0 && eof) {
+        if (member_open) e = "unexpected end of gzip stream";
+        break;
+      }
+      if (!member_open) {
+        // trailing zero padding after the last member is tolerated (as gzip(1) does)
+        bool all_zero = true;
+        for (uInt i = 0; i < zs.avail_in; ++i) if (zs.next_in[i]) { all_zero = false; break; }
+        if (all_zero) { zs.avail_in = 0; continue; }
+      }
+      zs.next_out = out.data() + have;
+      zs.avail_out = (uInt)(out.size() - have);
+      member_open = true;
+      int rc = inflate(&zs, Z_NO_FLUSH);
+      have = out.size() - zs.avail_out;
+      if (rc == Z_STREAM_END) {
+        member_open = false;
+        inflateReset(&zs);
+        if (range_end_u.load() == INT64_MAX && start_off + fed - (int64_t)zs.avail_in >= end_off)
+          range_end_u.store(pushed + (int64_t)have + 1);
+      } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+        e = std::string("inflate failed: ") + (zs.msg ? zs.msg : "data error");
+        break;
+      }
+      if (have == out.size()) {
+        pushed += (int64_t)have;
+        push(std::move(out));
+        out.assign(kBlock, 0);
+        have = 0;
+      }
+    }
+    inflateEnd(&zs);
+    if (e.empty() && have) {
+      out.resize(have);
+      push(std::move(out));
+    }
+    finish(e);
+  }
+
+  void start() {
+    th = std::thread([this] { compressed ? run_gzip() : run_plain(); });
+  }
+  ~Source() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      cancel = true;
+      cv_put.notify_all();
+    }
+    if (th.joinable()) th.join();
+    if (fp) fclose(fp);
+  }
+};
+
+int sniff(const char* path, int* type) {
+  FILE* fp = fopen(path, "rb");
+  if (!fp) return fail(DC_FQ_ERR_IO, "cannot open '%s': %s", path, strerror(errno));
+  unsigned char b[18] = {0};
+  size_t n = fread(b, 1, sizeof b, fp);
+  fclose(fp);
+  int t = DC_CT_UNKNOWN;
+  if (n < 2) t = DC_CT_UNCOMPRESS;
+  else if (n >= 18 && b[0] == 0x1f && b[1] == 0x8b && b[2] == 0x08 && b[3] == 0x04) {
+    unsigned xlen = b[10] | (b[11] << 8);
+    t = (xlen >= 6 && b[12] == 'B' && b[13] == 'C' && b[14] == 2 && b[15] == 0) ? DC_CT_BGZIP : DC_CT_GZIP;
+  } else if (b[0] == 0x1f && b[1] == 0x8b) t = DC_CT_GZIP;
+  else if (n >= 4 && b[0] == 'P' && b[1] == 'K' && ((b[2] == 3 && b[3] == 4) || (b[2] == 5 && b[3] == 6) || (b[2] == 7 && b[3] == 8))) t = DC_CT_ZIP;
+  else if (n >= 3 && b[0] == 'B' && b[1] == 'Z' && b[2] == 'h') t = DC_CT_BZIP2;
+  else if (n >= 6 && b[0] == 0xfd && b[1] == '7' && b[2] == 'z' && b[3] == 'X' && b[4] == 'Z' && b[5] == 0) t = DC_CT_XZ;
+  else if (n >= 4 && b[0] == 0x28 && b[1] == 0xb5 && b[2] == 0x2f && b[3] == 0xfd) t = DC_CT_ZSTD;
+  else t = DC_CT_UNCOMPRESS;  // no known signature: treated as plain text
+  *type = t;
+  return 0;
+}
+
+}  // namespace
+
+struct dc_fq_reader {
+  Source src;
+  std::string path;
+  std::vector<uint8_t> buf;  // pending bytes; buf[pos..] not yet parsed
+  size_t pos = 0;
+  int64_t base = 0;          // absolute (plain-file) offset of buf[0]
+  bool eof = false;
+  bool ranged = false, synced = true;
+  int64_t range_begin = 0, range_end = INT64_MAX;
+  int64_t n_records = 0;
+  bool finished = false;
+
+  int64_t range_limit() const { return src.compressed ? src.range_end_u.load() : range_end; }
+
+  // Drops the parsed prefix.  Only called between records, so indices held while a record is being
+  // parsed stay valid (more() appends, never moves).
+  void compact() {
+    if (pos >= kBlock) {
+      buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos);
+      base += (int64_t)pos;
+      pos = 0;
+    }
+  }
+
+  // appends the next block; false at end of stream (rc set on a source error)
+  bool more(int& rc) {
+    if (eof) return false;
+    std::vector<uint8_t> b;
+    std::string e;
+    if (!src.pop(b, e)) {
+      eof = true;
+      if (!e.empty()) rc = fail(DC_FQ_ERR_IO, "%s: %s", path.c_str(), e.c_str());
+      return false;
+    }
+    buf.insert(buf.end(), b.begin(), b.end());
+    return true;
+  }
+
+  // End of the line starting at `from`: *eol = index of its '\n', or buf.size() for an unterminated
+  // last line.  false = no line starts at `from` (end of input) or a source error (rc != 0).
+  bool line_end(size_t from, size_t* eol, int& rc) {
+    size_t scan = from;
+    for (;;) {
+      if (scan < buf.size()) {
+        const void* p = memchr(buf.data() + scan, '\n', buf.size() - scan);
+        if (p) { *eol = (size_t)((const uint8_t*)p - buf.data()); return true; }
+        scan = buf.size();
+      }
+      if (!more(rc)) {
+        if (rc || from >= buf.size()) return false;
+        *eol = buf.size();
+        return true;
+      }
+    }
+  }
+
+  size_t next_line(size_t eol) const { return eol < buf.size() ? eol + 1 : eol; }
+
+  // Byte-range shards: buf[pos] is file byte range_begin-1.  Move to the first line that starts at or
+  // after range_begin and begins a record: an '@' line whose next-but-one line starts with '+'
+  // (a quality line may start with '@', but then the next-but-one line is a sequence, never '+').
+  int sync_to_record(int& rc) {
+    size_t e;
+    if (!line_end(pos, &e, rc)) { finished = true; return rc; }
+    pos = next_line(e);
+    for (;;) {
+      compact();
+      size_t e1, e2, e3;
+      if (!line_end(pos, &e1, rc)) { finished = true; return rc; }
+      if (buf[pos] == '@' && e1 < buf.size() && line_end(e1 + 1, &e2, rc) && e2 < buf.size() &&
+          line_end(e2 + 1, &e3, rc) && buf[e2 + 1] == '+')
+        break;
+      if (rc) return rc;
+      pos = next_line(e1);
+    }
+    synced = true;
+    return 0;
+  }
+};
+
+extern "C" {
+
+const char* dc_io_last_error(void) { return g_err.c_str(); }
+
+int dc_io_check_compressed_type(const char* path, int* type_out) {
+  if (!path || !type_out) return fail(DC_FQ_ERR_ARG, "null argument");
+  return sniff(path, type_out);
+}
+
+// First BGZF block boundary at or after `want` (hopping block headers from the start of the file:
+// each header carries BSIZE = block length - 1 at bytes 16-17).  File size if none.
+static int bgzf_snap(FILE* fp, int64_t want, int64_t fsize, int64_t* snapped) {
+  int64_t off = 0;
+  unsigned char h[18];
+  while (off < want && off < fsize) {
+    if (fseeko(fp, (off_t)off, SEEK_SET) != 0 || fread(h, 1, 18, fp) != 18) return fail(DC_FQ_ERR_IO, "truncated BGZF block header at %lld", (long long)off);
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[12] != 'B' || h[13] != 'C')
+      return fail(DC_FQ_ERR_IO, "not a BGZF block at offset %lld", (long long)off);
+    off += (int64_t)(h[16] | (h[17] << 8)) + 1;
+  }
+  *snapped = off < fsize ? off : fsize;
+  return 0;
+}
+
+static int open_impl(const char* path, int64_t b0, int64_t b1, bool ranged, int readahead, dc_fq_reader** out) {
+  if (!path || !out) return fail(DC_FQ_ERR_ARG, "null argument");
+  int t = 0;
+  if (int rc = sniff(path, &t)) return rc;
+  if (t != DC_CT_UNCOMPRESS && t != DC_CT_GZIP && t != DC_CT_BGZIP)
+    return fail(DC_FQ_ERR_IO, "unsupported compression type");  // writefq.rs:159
+  if (ranged && t == DC_CT_GZIP) return fail(DC_FQ_ERR_ARG, "byte-range shards need an uncompressed or BGZF FASTQ (plain gzip cannot be entered mid-stream)");
+  if (ranged && (b0 < 0 || b1 < b0)) return fail(DC_FQ_ERR_ARG, "invalid byte range [%lld, %lld)", (long long)b0, (long long)b1);
+  std::unique_ptr<dc_fq_reader> r(new dc_fq_reader);
+  r->path = path;
+  r->src.fp = fopen(path, "rb");
+  if (!r->src.fp) return fail(DC_FQ_ERR_IO, "cannot open '%s': %s", path, strerror(errno));
+  r->src.compressed = t != DC_CT_UNCOMPRESS;
+  r->src.depth = readahead > 0 ? readahead : 4;
+  if (ranged && t == DC_CT_UNCOMPRESS) {
+    // ownership rule: a record belongs to the range that holds the byte BEFORE its '@' (record 0 to the
+    // range that starts at 0), so reading starts one byte early and ranges tile without gaps or overlap
+    r->ranged = true;
+    r->range_begin = b0;
+    r->range_end = b1;
+    int64_t start = b0 > 0 ? b0 - 1 : 0;
+    if (fseeko(r->src.fp, (off_t)start, SEEK_SET) != 0) return fail(DC_FQ_ERR_IO, "seek failed in '%s'", path);
+    r->base = start;
+    r->synced = b0 == 0;
+  } else if (ranged) {
+    // BGZF: the range is snapped to block boundaries (every rank computes the same snapping); positions
+    // are then decompressed offsets relative to the first block of the range, same ownership rule
+    if (fseeko(r->src.fp, 0, SEEK_END) != 0) return fail(DC_FQ_ERR_IO, "seek failed in '%s'", path);
+    int64_t fsize = (int64_t)ftello(r->src.fp), s0 = 0, s1 = 0;
+    if (int rc = bgzf_snap(r->src.fp, b0, fsize, &s0)) return rc;
+    if (int rc = bgzf_snap(r->src.fp, b1, fsize, &s1)) return rc;
+    if (fseeko(r->src.fp, (off_t)s0, SEEK_SET) != 0) return fail(DC_FQ_ERR_IO, "seek failed in '%s'", path);
+    r->ranged = true;
+    r->src.start_off = s0;
+    r->src.end_off = s1;
+    if (s1 <= s0) r->src.range_end_u.store(0);  // empty range
+    r->base = 0;  // stream byte 0 plays the part of "range_begin - 1"
+    r->synced = s0 == 0;
+  }
+  r->src.start();
+  *out = r.release();
+  return 0;
+}
+
+int dc_fq_open(const char* path, int readahead, dc_fq_reader** out) { return open_impl(path, 0, 0, false, readahead, out); }
+
+int dc_fq_open_range(const char* path, int64_t byte_begin, int64_t byte_end, int readahead, dc_fq_reader** out) {
+  return open_impl(path, byte_begin, byte_end, true, readahead, out);
+}
+
+int64_t dc_fq_records_read(const dc_fq_reader* r) { return r ? r->n_records : 0; }
+int64_t dc_fq_bytes_consumed(const dc_fq_reader* r) { return r ? r->src.consumed.load() : 0; }
+void dc_fq_close(dc_fq_reader* r) { delete r; }
+
+int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
+                     int64_t* offsets, char* names, int64_t cap_names, int64_t* name_offsets, int64_t* n_reads) {
+  if (!r || !seq || !qual || !offsets || !names || !name_offsets || !n_reads || max_reads < 0 || cap_bases < 0 || cap_names < 0)
+    return fail(DC_FQ_ERR_ARG, "invalid argument");
+  int rc = 0;
+  int64_t n = 0, nb = 0, nn = 0;
+  offsets[0] = 0;
+  name_offsets[0] = 0;
+  *n_reads = 0;
+  if (r->ranged && !r->synced && !r->finished) {
+    if (r->sync_to_record(rc)) return rc;
+  }
+  while (n < max_reads && !r->finished) {
+    r->compact();
+    // skip blank lines between records
+    size_t e[4];
+    for (;;) {
+      if (!r->line_end(r->pos, &e[0], rc)) {
+        if (rc) return rc;
+        r->finished = true;
+        break;
+      }
+      size_t len = e[0] - r->pos;
+      if (len == 0 || (len == 1 && r->buf[r->pos] == '\r')) { r->pos = r->next_line(e[0]); continue; }
+      break;
+    }
+    if (r->finished) break;
+    if (r->ranged && r->base + (int64_t)r->pos >= r->range_limit()) { r->finished = true; break; }
+    bool ok = true;
+    for (int k = 1; k < 4 && ok; ++k) ok = e[k - 1] < r->buf.size() && r->line_end(e[k - 1] + 1, &e[k], rc);
+    if (rc) return rc;
+    int64_t recno = r->n_records;
+    if (!ok) return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: truncated record %lld", r->path.c_str(), (long long)recno);
+    const uint8_t* d = r->buf.data();
+    size_t s0 = r->pos, s1 = e[0] + 1, s2 = e[1] + 1, s3 = e[2] + 1;
+    auto strip = [&](size_t a, size_t b) { while (b > a && (d[b - 1] == '\r')) --b; return b; };
+    size_t h_end = strip(s0, e[0]), q_end = strip(s3, e[3]), sq_end = strip(s1, e[1]);
+    if (d[s0] != '@')
+      return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: record %lld does not start with '@'", r->path.c_str(), (long long)recno);
+    if (s2 >= r->buf.size() || d[s2] != '+')
+      return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: record %lld has no '+' separator", r->path.c_str(), (long long)recno);
+    size_t nm0 = s0 + 1, nm1 = nm0;
+    while (nm1 < h_end && d[nm1] != ' ' && d[nm1] != '\t') ++nm1;
+    int64_t ls = (int64_t)(sq_end - s1), lq = (int64_t)(q_end - s3), ln = (int64_t)(nm1 - nm0);
+    if (ln == 0 || ls == 0 || lq == 0)
+      return fail(DC_FQ_ERR_INCOMPLETE, "Incomplete FASTQ record at position %lld in %s", (long long)recno, r->path.c_str());
+    if (ls != lq)
+      return fail(DC_FQ_ERR_LENGTH, "Sequence/quality length mismatch in record '%.*s': seq=%lld, qual=%lld", (int)ln,
+                  (const char*)d + nm0, (long long)ls, (long long)lq);
+    if (nb + ls > cap_bases || nn + ln > cap_names) {
+      if (n == 0) return fail(DC_FQ_ERR_ARG, "record '%.*s' (%lld bases) does not fit the chunk buffers", (int)ln, (const char*)d + nm0, (long long)ls);
+      break;  // deliver what we have; this record starts the next chunk
+    }
+    memcpy(seq + nb, d + s1, (size_t)ls);
+    memcpy(qual + nb, d + s3, (size_t)ls);
+    memcpy(names + nn, d + nm0, (size_t)ln);
+    nb += ls;
+    nn += ln;
+    ++n;
+    offsets[n] = nb;
+    name_offsets[n] = nn;
+    ++r->n_records;
+    r->pos = r->next_line(e[3]);
+  }
+  *n_reads = n;
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// BGZF writer: blocks of <= 65280 input bytes, each an independent gzip member with the BC extra
+// field; N workers compress, the caller's thread writes finished blocks in submission order.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kBgzfIn = 0xff00;
+const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0,
+                                    0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct Job {
+  std::vector<uint8_t> in, out;
+  bool done = false, failed = false;
+};
+
+bool bgzf_compress(z_stream& zs, int level, Job& j) {
+  auto attempt = [&](int lvl) -> bool {
+    if (deflateParams(&zs, lvl, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    deflateReset(&zs);
+    j.out.resize(18 + deflateBound(&zs, (uLong)j.in.size()) + 8);
+    zs.next_in = j.in.data();
+    zs.avail_in = (uInt)j.in.size();
+    zs.next_out = j.out.data() + 18;
+    zs.avail_out = (uInt)(j.out.size() - 18 - 8);
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return false;
+    size_t clen = j.out.size() - 18 - 8 - zs.avail_out;
+    size_t total = 18 + clen + 8;
+    if (total > 65536) return false;
+    uint8_t* h = j.out.data();
+    const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 'B', 'C', 0x02, 0};
+    memcpy(h, head, 16);
+    h[16] = (uint8_t)((total - 1) & 0xff);
+    h[17] = (uint8_t)((total - 1) >> 8);
+    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j.in.data(), (uInt)j.in.size());
+    uint32_t isize = (uint32_t)j.in.size();
+    uint8_t* t = h + 18 + clen;
+    for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)(isize >> (8 * k)); }
+    j.out.resize(total);
+    return true;
+  };
+  return attempt(level) || attempt(0);  // incompressible data: stored block still fits (65280 + 5 + 26)
+}
+}  // namespace
+
+struct dc_bgzf_writer {
+  FILE* fp = nullptr;
+  int level = 6;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<Job*> todo;                       // waiting for a worker
+  std::deque<std::unique_ptr<Job>> inflight;   // submission order
+  size_t max_inflight = 8;
+  bool stop = false;
+  std::unique_ptr<Job> cur;
+  bool io_failed = false;
+
+  void worker() {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    bool ok = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+    for (;;) {
+      Job* j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_work.wait(lk, [&] { return stop || !todo.empty(); });
+        if (todo.empty()) break;
+        j = todo.front();
+        todo.pop_front();
+      }
+      bool good = ok && bgzf_compress(zs, level, *j);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        j->failed = !good;
+        j->done = true;
+      }
+      cv_done.notify_all();
+    }
+    if (ok) deflateEnd(&zs);
+  }
+
+  // write finished blocks at the head; if `all`, wait until everything in flight is written
+  int drain(bool all, size_t keep) {
+    for (;;) {
+      std::unique_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (inflight.empty()) return 0;
+        if (!inflight.front()->done) {
+          if (!all && inflight.size() <= keep) return 0;
+          cv_done.wait(lk, [&] { return inflight.front()->done; });
+        }
+        j = std::move(inflight.front());
+        inflight.pop_front();
+      }
+      if (j->failed) return fail(DC_FQ_ERR_IO, "BGZF block compression failed");
+      if (fwrite(j->out.data(), 1, j->out.size(), fp) != j->out.size()) {
+        io_failed = true;
+        return fail(DC_FQ_ERR_IO, "write failed: %s", strerror(errno));
+      }
+    }
+  }
+
+  int submit() {
+    if (!cur || cur->in.empty()) return 0;
+    Job* raw = cur.get();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      inflight.emplace_back(std::move(cur));
+      todo.push_back(raw);
+    }
+    cv_work.notify_one();
+    cur.reset(new Job);
+    cur->in.reserve(kBgzfIn);
+    return drain(false, max_inflight);
+  }
+
+  int put(const uint8_t* p, size_t n) {
+    while (n) {
+      size_t room = kBgzfIn - cur->in.size();
+      size_t k = n < room ? n : room;
+      cur->in.insert(cur->in.end(), p, p + k);
+      p += k;
+      n -= k;
+      if (cur->in.size() == kBgzfIn)
+        if (int rc = submit()) return rc;
+    }
+    return 0;
+  }
+};
+
+extern "C" {
+
+int dc_bgzf_open(const char* path, int threads, int level, dc_bgzf_writer** out) {
+  if (!path || !out || threads < 1 || level < 0 || level > 9) return fail(DC_FQ_ERR_ARG, "invalid argument");
+  std::unique_ptr<dc_bgzf_writer> w(new dc_bgzf_writer);
+  w->fp = fopen(path, "wb");
+  if (!w->fp) return fail(DC_FQ_ERR_IO, "cannot create '%s': %s", path, strerror(errno));
+  w->level = level == 0 ? 6 : level;
+  w->max_inflight = (size_t)threads * 4;
+  w->cur.reset(new Job);
+  w->cur->in.reserve(kBgzfIn);
+  dc_bgzf_writer* raw = w.get();
+  for (int i = 0; i < threads; ++i) w->workers.emplace_back([raw] { raw->worker(); });
+  *out = w.release();
+  return 0;
+}
+
+int dc_bgzf_write(dc_bgzf_writer* w, const void* data, int64_t n) {
+  if (!w || (!data && n) || n < 0) return fail(DC_FQ_ERR_ARG, "invalid argument");
+  return w->put((const uint8_t*)data, (size_t)n);
+}
+
+int dc_bgzf_write_fastq(dc_bgzf_writer* w, int64_t n, const char* names, const int64_t* name_offsets,
+                        const uint8_t* seq, const uint8_t* qual, const int64_t* offsets) {
+  if (!w || n < 0 || (n && (!names || !name_offsets || !seq || !qual || !offsets))) return fail(DC_FQ_ERR_ARG, "invalid argument");
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t a = offsets[i], b = offsets[i + 1], na = name_offsets[i], nb = name_offsets[i + 1];
+    if (b < a || nb < na) return fail(DC_FQ_ERR_ARG, "offsets not monotonic at record %lld", (long long)i);
+    int rc = 0;
+    if ((rc = w->put((const uint8_t*)"@", 1)) || (rc = w->put((const uint8_t*)names + na, (size_t)(nb - na))) ||
+        (rc = w->put((const uint8_t*)"\n", 1)) || (rc = w->put(seq + a, (size_t)(b - a))) ||
+        (rc = w->put((const uint8_t*)"\n+\n", 3)) || (rc = w->put(qual + a, (size_t)(b - a))) ||
+        (rc = w->put((const uint8_t*)"\n", 1)))
+      return rc;
+  }
+  return 0;
+}
+
+int dc_bgzf_close(dc_bgzf_writer* w) {
+  if (!w) return fail(DC_FQ_ERR_ARG, "null writer");
+  int rc = w->submit();
+  int rc2 = w->drain(true, 0);
+  if (!rc) rc = rc2;
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->stop = true;
+  }
+  w->cv_work.notify_all();
+  for (auto& t : w->workers) t.join();
+  if (!rc && fwrite(kBgzfEof, 1, sizeof kBgzfEof, w->fp) != sizeof kBgzfEof) rc = fail(DC_FQ_ERR_IO, "write failed");
+  if (fclose(w->fp) != 0 && !rc) rc = fail(DC_FQ_ERR_IO, "close failed: %s", strerror(errno));
+  delete w;
+  return rc;
+}
+
+}  // extern "C"

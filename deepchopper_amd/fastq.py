@@ -1,44 +1,183 @@
-"""Streaming FASTQ reader (plain / gzip) with the validation rules of `parse_fastq_file`
+"""Streaming FASTQ reader (plain / gzip / BGZF) and multithreaded BGZF writer on the native host
+library (include/deepchopper_io.h), with the validation rules of `parse_fastq_file`
 (deepchopper/data/only_fq.py:21-85): every record needs a name, a sequence and a quality string of
-equal length; an empty file is an error."""
+equal length; an empty file is an error.
+
+The reader's unit is a *chunk*: packed `seq` / `qual` bytes + `offsets` -- exactly what
+`dc_tokenize_batch` takes -- so a batch goes from file bytes to the GPU without a Python object per
+read.  `iter_fastq` keeps the per-record view for small inputs and the chop driver.
+"""
 from __future__ import annotations
 
-import gzip
+import ctypes as C
+import os
 from typing import Iterator
 
+import numpy as np
 
-def _open(path: str):
-    with open(path, "rb") as fh:
-        magic = fh.read(2)
-    return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+from . import _iolib
+
+
+def check_compressed_type(path: str) -> str:
+    """check_compressed_type (src/output/writefq.rs:84-147): one of _iolib.COMPRESSED_TYPES."""
+    t = C.c_int(0)
+    _iolib.raise_for(_iolib.lib().dc_io_check_compressed_type(os.fsencode(path), C.byref(t)))
+    return _iolib.COMPRESSED_TYPES[t.value]
+
+
+class FastqChunk:
+    """n reads as packed buffers (views into the reader's reusable arrays: copy to keep)."""
+
+    __slots__ = ("n", "seq", "qual", "offsets", "_names", "_name_offsets")
+
+    def __init__(self, n, seq, qual, offsets, names, name_offsets):
+        self.n, self.seq, self.qual, self.offsets = n, seq, qual, offsets
+        self._names, self._name_offsets = names, name_offsets
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.offsets)
+
+    def head(self, k: int) -> "FastqChunk":
+        """The first k reads of the chunk."""
+        k = max(0, min(int(k), self.n))
+        nb, nn = int(self.offsets[k]), int(self._name_offsets[k])
+        return FastqChunk(k, self.seq[:nb], self.qual[:nb], self.offsets[: k + 1], self._names[:nn], self._name_offsets[: k + 1])
+
+    def names(self) -> list[str]:
+        raw = self._names.tobytes()
+        o = self._name_offsets
+        return [raw[o[i]: o[i + 1]].decode("latin1") for i in range(self.n)]
+
+    def records(self) -> Iterator[tuple[str, bytes, bytes]]:
+        s, q, o = self.seq.tobytes(), self.qual.tobytes(), self.offsets
+        for i, name in enumerate(self.names()):
+            yield name, s[o[i]: o[i + 1]], q[o[i]: o[i + 1]]
+
+
+class FastqReader:
+    """StreamingFastqReader (src/output/writefq.rs:172-199) + parse_fastq_file's validation.
+
+    `byte_range=(b0, b1)` opens a shard of an uncompressed file: the records whose '@' line starts in
+    [b0, b1) -- ranks tile the file with `shard_byte_range` and never parse each other's reads."""
+
+    def __init__(self, path: str, *, byte_range: tuple[int, int] | None = None, readahead: int = 4):
+        self.path = str(path)
+        self._h = C.c_void_p()
+        L = _iolib.lib()
+        if byte_range is None:
+            rc = L.dc_fq_open(os.fsencode(self.path), readahead, C.byref(self._h))
+        else:
+            rc = L.dc_fq_open_range(os.fsencode(self.path), int(byte_range[0]), int(byte_range[1]), readahead, C.byref(self._h))
+        if rc:
+            self._h = C.c_void_p()
+            _iolib.raise_for(rc)
+        self._cap = (0, 0, 0)
+        self._bufs = None
+
+    def _buffers(self, max_reads: int, cap_bases: int, cap_names: int):
+        if self._cap != (max_reads, cap_bases, cap_names):
+            self._bufs = (np.empty(cap_bases, np.uint8), np.empty(cap_bases, np.uint8), np.empty(max_reads + 1, np.int64),
+                          np.empty(cap_names, np.uint8), np.empty(max_reads + 1, np.int64))
+            self._cap = (max_reads, cap_bases, cap_names)
+        return self._bufs
+
+    def read_chunk(self, max_reads: int = 4096, cap_bases: int = 8 << 20, cap_names: int | None = None) -> FastqChunk | None:
+        """Up to max_reads records / cap_bases bases; None at end of input.  The returned arrays are
+        reused by the next call."""
+        if not self._h:
+            raise ValueError("reader is closed")
+        cap_names = cap_names or max(256 * max_reads, 1 << 16)
+        seq, qual, offs, names, noffs = self._buffers(max_reads, cap_bases, cap_names)
+        n = C.c_int64(0)
+        rc = _iolib.lib().dc_fq_read_chunk(self._h, max_reads, seq.ctypes.data, qual.ctypes.data, cap_bases, offs.ctypes.data,
+                                           names.ctypes.data, cap_names, noffs.ctypes.data, C.byref(n))
+        _iolib.raise_for(rc)
+        k = n.value
+        if k == 0:
+            return None
+        nb = int(offs[k])
+        return FastqChunk(k, seq[:nb], qual[:nb], offs[: k + 1], names[: int(noffs[k])], noffs[: k + 1])
+
+    def chunks(self, max_reads: int = 4096, cap_bases: int = 8 << 20) -> Iterator[FastqChunk]:
+        while True:
+            c = self.read_chunk(max_reads, cap_bases)
+            if c is None:
+                return
+            yield c
+
+    @property
+    def records_read(self) -> int:
+        return int(_iolib.lib().dc_fq_records_read(self._h)) if self._h else 0
+
+    @property
+    def bytes_consumed(self) -> int:
+        return int(_iolib.lib().dc_fq_bytes_consumed(self._h)) if self._h else 0
+
+    def close(self) -> None:
+        if self._h:
+            _iolib.lib().dc_fq_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def shard_byte_range(path: str, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous byte slice of an uncompressed FASTQ for `rank` (contiguous read ranges
+    per GPU).  Slices tile [0, size); FastqReader(byte_range=...) snaps them to record boundaries."""
+    size = os.path.getsize(path)
+    return size * rank // world, size * (rank + 1) // world
 
 
 def iter_fastq(path: str, max_records: int | None = None) -> Iterator[tuple[str, bytes, bytes]]:
     """Yields (name, seq, qual); name = the definition line up to the first blank (what pyfastx's
     `Fastx` iterator returns as `name`)."""
     n = 0
-    with _open(path) as fh:
-        while True:
-            head = fh.readline()
-            if not head:
-                break
-            if not head.strip():
-                continue
-            if not head.startswith(b"@"):
-                raise RuntimeError(f"FASTQ parsing error in {path}: record {n} does not start with '@'")
-            seq = fh.readline().rstrip(b"\r\n")
-            plus = fh.readline()
-            qual = fh.readline().rstrip(b"\r\n")
-            if not plus.startswith(b"+"):
-                raise RuntimeError(f"FASTQ parsing error in {path}: record {n} has no '+' separator")
-            name = head[1:].rstrip(b"\r\n").split(b" ", 1)[0].split(b"\t", 1)[0].decode("latin1")
-            if not name or not seq or not qual:
-                raise ValueError(f"Incomplete FASTQ record at position {n} in {path}")
-            if len(seq) != len(qual):
-                raise ValueError(f"Sequence/quality length mismatch in record '{name}': seq={len(seq)}, qual={len(qual)}")
-            yield name, seq, qual
-            n += 1
-            if max_records is not None and n >= max_records:
-                break
+    with FastqReader(path) as rd:
+        for chunk in rd.chunks():
+            for rec in chunk.records():
+                yield rec
+                n += 1
+                if max_records is not None and n >= max_records:
+                    return
     if n == 0:
         raise ValueError(f"No valid records found in {path}")
+
+
+class BgzfWriter:
+    """bgzf::io::MultithreadedWriter as the reference uses it for FASTQ output
+    (src/output/writefq.rs:252-276, src/bin/predict.rs:266-270)."""
+
+    def __init__(self, path: str, threads: int = 2, level: int = 6):
+        self._h = C.c_void_p()
+        _iolib.raise_for(_iolib.lib().dc_bgzf_open(os.fsencode(str(path)), max(1, int(threads)), level, C.byref(self._h)))
+
+    def write(self, data: bytes) -> None:
+        _iolib.raise_for(_iolib.lib().dc_bgzf_write(self._h, data, len(data)))
+
+    def write_record(self, name: bytes, seq: bytes, qual: bytes) -> None:
+        self.write(b"@" + name + b"\n" + seq + b"\n+\n" + qual + b"\n")
+
+    def write_chunk(self, chunk: FastqChunk) -> None:
+        """Packed records straight from a reader chunk (no per-record Python objects)."""
+        _iolib.raise_for(_iolib.lib().dc_bgzf_write_fastq(
+            self._h, chunk.n, chunk._names.ctypes.data, chunk._name_offsets.ctypes.data, chunk.seq.ctypes.data,
+            chunk.qual.ctypes.data, chunk.offsets.ctypes.data))
+
+    def close(self) -> None:
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            _iolib.raise_for(_iolib.lib().dc_bgzf_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        self.close()

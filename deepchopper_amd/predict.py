@@ -120,6 +120,83 @@ class PredictPipeline:
         return out, res
 
 
+    # ---- streaming: FASTQ chunks -> labels / intervals, host I/O overlapped with GPU work ---------------
+    def _collect(self, names, lens, seq_h, qual_h, offs_h, d_in, res):
+        """D2H of one finished batch (blocks until the GPU is done with it)."""
+        net = self.model.net
+        torch.cuda.current_stream().synchronize()
+        if net.gemm_mode == "fp16x3" and net.overflow() > 0:
+            net.set_gemm_mode("bf16x6")  # an activation left the fp16 range: redo with the fp32-range split
+            try:
+                res = self.run_device_batch(*d_in, lens)
+                torch.cuda.current_stream().synchronize()
+            finally:
+                net.set_gemm_mode("fp16x3")
+        status = res["tok"]["status"].cpu().numpy()
+        check_read_status(status, names)
+        sm = res["smooth"]
+        return {
+            "names": names, "lengths": lens, "seq": seq_h, "qual": qual_h, "in_offsets": offs_h,
+            "offsets": sm["offsets"].cpu().numpy(), "pred": sm["pred"].cpu().numpy(), "smooth": sm["smooth"].cpu().numpy(),
+            "intervals": sm["intervals"].cpu().numpy(), "n_intervals": sm["n_intervals"].cpu().numpy(),
+            "keep": sm["keep"].cpu().numpy(), "n_keep": sm["n_keep"].cpu().numpy(), "truncated": (status & 1) != 0,
+            "device": res,  # device-resident tensors of the batch (logits, token matrices) for write_pt_batch
+        }
+
+    def predict_stream(self, chunks, *, prefetch: int = 2):
+        """`chunks`: an iterator of fastq.FastqChunk (e.g. `FastqReader.chunks(max_reads, max_tokens)`).
+        Yields one result dict per chunk, in input order: names, lengths, packed per-base labels
+        (`pred`, `smooth` + `offsets`), `intervals` / `n_intervals`, `keep` / `n_keep`, `truncated`.
+
+        Three things overlap: a helper thread parses (and inflates) the next chunks; the GPU runs batch k
+        (all launches are asynchronous); the host collects and hands out batch k-1.  Every read runs at
+        its own length (native mode, == the reference at --batch-size 1)."""
+        import queue
+        import threading
+
+        q: queue.Queue = queue.Queue(maxsize=max(1, prefetch))
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for c in chunks:
+                    item = (c.names(), c.lengths.copy(), c.seq.copy(), c.qual.copy(), c.offsets.copy())
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:  # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        pending = None
+        try:
+            while True:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                if item is not None:
+                    names, lens, seq_h, qual_h, offs_h = item
+                    d_in = (ops.to_device(seq_h), ops.to_device(qual_h), ops.to_device(offs_h))
+                    launched = (names, lens, seq_h, qual_h, offs_h, d_in, self.run_device_batch(*d_in, lens))
+                else:
+                    launched = None
+                if pending is not None:
+                    yield self._collect(*pending)
+                pending = launched
+                if item is None:
+                    break
+        finally:
+            stop.set()
+            th.join(timeout=5)
+
+
 def write_pt_batch(path: str, res: dict, ids: list[str]) -> None:
     """CustomWriter.write_on_batch_end (callbacks.py:12-25): the reference's predict -> chop wire
     format, `{prediction f32[B,L,2], target i64[B,L], seq i64[B,L], qual f32[B,L], id i64[B,256]}`."""

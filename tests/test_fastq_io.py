@@ -1,0 +1,290 @@
+"""Host-side FASTQ / gzip / BGZF I/O (include/deepchopper_io.h) against a plain-Python
+checker, the reference's own writefq.rs test vectors (src/output/writefq.rs:352-470) and Python's gzip
+module as an independent BGZF/gzip decoder.  No GPU involved."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from deepchopper_amd import _iolib
+from deepchopper_amd.fastq import (BgzfWriter, FastqReader, check_compressed_type, iter_fastq, shard_byte_range)
+
+
+def _py_parse(data: bytes):
+    """Checker: 4-line FASTQ, name up to the first blank."""
+    lines = [l.rstrip(b"\r") for l in data.split(b"\n")]
+    out, i = [], 0
+    while i < len(lines):
+        if not lines[i]:
+            i += 1
+            continue
+        out.append((lines[i][1:].split(b" ")[0].split(b"\t")[0].decode("latin1"), lines[i + 1], lines[i + 3]))
+        i += 4
+    return out
+
+
+def _random_fastq(n, seed, max_len=3000, tricky=True):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(1, max_len))
+        s = bytes(rng.choice(list(b"ACGTN"), L).astype(np.uint8))
+        q = bytearray(rng.integers(33, 127, L).astype(np.uint8).tobytes())
+        if tricky and i % 3 == 0:
+            q[0] = ord("@")  # quality lines that look like headers (the shard sync must not be fooled)
+        if tricky and i % 5 == 0:
+            q[0] = ord("+")
+        recs.append((f"read_{i:06d}", s, bytes(q)))
+    text = b"".join(b"@" + n_.encode() + b" some description\n" + s + b"\n+\n" + q + b"\n" for n_, s, q in recs)
+    return recs, text
+
+
+def test_io_library_exports_every_header_symbol():
+    lib = _iolib.lib()
+    syms = _iolib.header_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/deepchopper_io.h but not exported"
+    assert set(syms) == set(_iolib._SIGNATURES)
+
+
+def test_check_compressed_type(tmp_path):
+    """check_compressed_type (writefq.rs:84-147) signatures."""
+    cases = {
+        "Uncompress": b"@r\nACGT\n+\nIIII\n",
+        "Gzip": gzip.compress(b"hello"),
+        "Zip": b"PK\x03\x04" + b"\0" * 20,
+        "Bzip2": b"BZh91AY&SY" + b"\0" * 10,
+        "Xz": b"\xfd7zXZ\x00" + b"\0" * 14,
+        "Zstd": b"\x28\xb5\x2f\xfd" + b"\0" * 16,
+    }
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert check_compressed_type(str(p)) == name
+    p = tmp_path / "b.gz"
+    with BgzfWriter(str(p)) as w:
+        w.write(b"x")
+    assert check_compressed_type(str(p)) == "Bgzip"
+    (tmp_path / "tiny").write_bytes(b"@")
+    assert check_compressed_type(str(tmp_path / "tiny")) == "Uncompress"  # < 2 bytes
+    with pytest.raises(RuntimeError, match="cannot open"):
+        check_compressed_type(str(tmp_path / "missing"))
+    for name in ("Zip", "Bzip2", "Xz", "Zstd"):
+        with pytest.raises(RuntimeError, match="unsupported compression type"):  # writefq.rs:159
+            FastqReader(str(tmp_path / name))
+
+
+def test_reader_matches_checker_on_reference_fixtures(golden_dir):
+    for f, n in (("one_record.fq", 1), ("twenty_five_records.fq", 25), ("simple.fq", 1)):
+        path = os.path.join(golden_dir, f)
+        exp = _py_parse(open(path, "rb").read())
+        got = list(iter_fastq(path))
+        assert len(got) == n and got == exp
+
+
+@pytest.mark.parametrize("container", ["plain", "gzip", "multi_member_gzip", "bgzf"])
+def test_reader_containers_and_chunking(tmp_path, container):
+    recs, text = _random_fastq(3000, seed=1)
+    p = str(tmp_path / "a.fq")
+    if container == "plain":
+        open(p, "wb").write(text)
+    elif container == "gzip":
+        open(p, "wb").write(gzip.compress(text, 1))
+    elif container == "multi_member_gzip":
+        cut = [0, 1, 70000, 70001, len(text) // 2, len(text)]
+        open(p, "wb").write(b"".join(gzip.compress(text[a:b], 1) for a, b in zip(cut, cut[1:])) + b"\0" * 512)
+    else:
+        with BgzfWriter(p, threads=3) as w:
+            for i in range(0, len(text), 99991):
+                w.write(text[i: i + 99991])
+    assert list(iter_fastq(p)) == recs
+    # ragged chunk limits: by reads and by bases; buffers are reused, names / offsets stay consistent
+    with FastqReader(p) as rd:
+        seen, sizes = [], []
+        for c in rd.chunks(max_reads=257, cap_bases=200_000):
+            assert c.n <= 257 and int(c.offsets[-1]) <= 200_000 and c.offsets[0] == 0
+            assert np.array_equal(c.lengths, [len(s) for _, s, _ in recs[len(seen): len(seen) + c.n]])
+            seen += list(c.records())
+            sizes.append(c.n)
+        assert seen == recs and rd.records_read == len(recs) and rd.bytes_consumed == os.path.getsize(p)
+        assert rd.read_chunk() is None  # stays at end of input
+    assert len(set(sizes)) > 1
+
+
+def test_reader_edge_cases(tmp_path):
+    def parse(blob, **kw):
+        p = tmp_path / "e.fq"
+        p.write_bytes(blob)
+        return list(iter_fastq(str(p), **kw))
+
+    assert parse(b"@r1 d\r\nACGT\r\n+\r\nIIII\r\n@r2\tx\nAC\n+r2\nII") == [("r1", b"ACGT", b"IIII"), ("r2", b"AC", b"II")]
+    assert parse(b"\n\n@r1\nA\n+\nI\n\n\n@r2\nC\n+\nJ\n\n") == [("r1", b"A", b"I"), ("r2", b"C", b"J")]
+    assert parse(b"@a\nA\n+\nI\n@b\nC\n+\nJ\n@c\nG\n+\nK\n", max_records=2) == [("a", b"A", b"I"), ("b", b"C", b"J")]
+    big = b"@big\n" + b"A" * (9 << 20) + b"\n+\n" + b"I" * (9 << 20) + b"\n@s\nC\n+\nJ\n"  # record spans source blocks
+    p = tmp_path / "big.fq"
+    p.write_bytes(big)
+    with FastqReader(str(p)) as rd:
+        c = rd.read_chunk(max_reads=8, cap_bases=10 << 20)
+        assert c.n == 2 and c.names() == ["big", "s"] and c.lengths.tolist() == [9 << 20, 1]
+    with FastqReader(str(p)) as rd, pytest.raises(ValueError, match="does not fit"):
+        rd.read_chunk(max_reads=8, cap_bases=1 << 20)
+    # parse_fastq_file's validation (only_fq.py:38-45) and pyfastx-style parse failures
+    with pytest.raises(ValueError, match="Sequence/quality length mismatch in record 'r1': seq=4, qual=2"):
+        parse(b"@r1\nACGT\n+\nII\n")
+    with pytest.raises(ValueError, match="Incomplete FASTQ record at position 1"):
+        parse(b"@r0\nA\n+\nI\n@\nACGT\n+\nIIII\n")
+    with pytest.raises(ValueError, match="Incomplete FASTQ record at position 0"):
+        parse(b"@r1\n\n+\n\n")
+    with pytest.raises(RuntimeError, match="does not start with '@'"):
+        parse(b"r1\nACGT\n+\nIIII\n")
+    with pytest.raises(RuntimeError, match="no '\\+' separator"):
+        parse(b"@r1\nACGT\nIIII\n@r2\n")
+    with pytest.raises(RuntimeError, match="truncated record 1"):
+        parse(b"@r0\nA\n+\nI\n@r1\nACGT\n+\n")
+    with pytest.raises(ValueError, match="No valid records"):
+        parse(b"")
+    with pytest.raises(ValueError, match="No valid records"):
+        parse(b"\n\n\n")
+    bad = tmp_path / "bad.gz"
+    blob = gzip.compress(b"@r\nACGT\n+\nIIII\n" * 1000)
+    bad.write_bytes(blob[: len(blob) // 2])
+    with pytest.raises(RuntimeError, match="gzip|inflate"):
+        list(iter_fastq(str(bad)))
+
+
+@pytest.mark.parametrize("container", ["plain", "bgzf"])
+def test_byte_range_shards_tile_the_file(tmp_path, container):
+    """Every record exactly once and in order for any world size, including quality lines that begin
+    with '@' or '+', ranges smaller than a record and empty ranges (contiguous shards)."""
+    recs, text = _random_fastq(1500, seed=2, max_len=400)
+    p = str(tmp_path / "s.fq")
+    if container == "plain":
+        open(p, "wb").write(text)
+    else:
+        with BgzfWriter(p, threads=2, level=1) as w:
+            w.write(text)
+    names = [r[0] for r in recs]
+    for world in (1, 2, 3, 8, 61, 5000):
+        got, per_rank = [], []
+        for rank in range(world):
+            with FastqReader(p, byte_range=shard_byte_range(p, rank, world)) as rd:
+                mine = [n for c in rd.chunks(max_reads=100) for n in c.names()]
+            per_rank.append(len(mine))
+            got += mine
+        assert got == names, world
+        if world == 8 and container == "plain":
+            assert max(per_rank) - min(per_rank) < 0.2 * len(names) / world + 5
+    size = os.path.getsize(p)
+    for b0, b1 in ((0, 0), (size, size), (size - 1, size), (size + 10, size + 20), (5, 5)):
+        with FastqReader(p, byte_range=(b0, b1)) as rd:
+            assert rd.read_chunk() is None
+    with pytest.raises(ValueError, match="invalid byte range"):
+        FastqReader(p, byte_range=(10, 5))
+    gz = str(tmp_path / "s.fq.gz")
+    open(gz, "wb").write(gzip.compress(text, 1))
+    with pytest.raises(ValueError, match="cannot be entered mid-stream"):
+        FastqReader(gz, byte_range=(0, 100))
+
+
+def _bgzf_blocks(blob):
+    off, blocks = 0, []
+    while off < len(blob):
+        magic, xlen = blob[off: off + 4], struct.unpack_from("<H", blob, off + 10)[0]
+        assert magic == b"\x1f\x8b\x08\x04" and xlen == 6 and blob[off + 12: off + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", blob, off + 16)[0] + 1
+        crc, isize = struct.unpack_from("<II", blob, off + bsize - 8)
+        blocks.append((off, bsize, isize, crc))
+        off += bsize
+    assert off == len(blob)
+    return blocks
+
+
+@pytest.mark.parametrize("threads,level", [(1, 6), (4, 1), (3, 9)])
+def test_bgzf_writer_format(tmp_path, threads, level):
+    rng = np.random.default_rng(3)
+    payload = rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes() + b"ACGT" * 100_000  # incompressible + compressible
+    p = tmp_path / "w.gz"
+    with BgzfWriter(str(p), threads=threads, level=level) as w:
+        for i in range(0, len(payload), 7919):
+            w.write(payload[i: i + 7919])
+        w.write(b"")
+    blob = p.read_bytes()
+    assert gzip.decompress(blob) == payload  # any gzip reader decodes BGZF
+    blocks = _bgzf_blocks(blob)
+    assert blob.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # EOF marker block
+    assert blocks[-1][2] == 0 and all(b[1] <= 65536 and b[2] <= 65280 for b in blocks)
+    assert sum(b[2] for b in blocks) == len(payload)
+    import zlib
+    off = 0
+    for o, bsize, isize, crc in blocks:  # every block is independently decodable with a matching CRC
+        raw = zlib.decompress(blob[o + 18: o + bsize - 8], -15)
+        assert len(raw) == isize and zlib.crc32(raw) == crc and raw == payload[off: off + isize]
+        off += isize
+    # output does not depend on the number of workers
+    q = tmp_path / "w1.gz"
+    with BgzfWriter(str(q), threads=1, level=level) as w:
+        w.write(payload)
+    assert q.read_bytes() == blob
+    e = tmp_path / "empty.gz"
+    BgzfWriter(str(e)).close()
+    assert len(e.read_bytes()) == 28 and gzip.decompress(e.read_bytes()) == b""
+    with pytest.raises(RuntimeError, match="cannot create"):
+        BgzfWriter(str(tmp_path / "no_such_dir" / "x.gz"))
+
+
+def test_reference_writefq_vectors(tmp_path):
+    """src/output/writefq.rs tests: test_streaming_fastq_reader (:352-404), test_write_fq_with_file_path
+    (:406-426: exact text "@1\\nATCG\\n+\\nHHHH\\n@2\\nGCTA\\n+\\nMMMM\\n"), test_write_fq_parallel (:428-470)."""
+    three = [(b"read1", b"ATCGATCG", b"IIIIIIII"), (b"read2", b"GCTAGCTA", b"HHHHHHHH"), (b"read3", b"AAAATTTT", b"JJJJJJJJ")]
+    p = str(tmp_path / "t.fq.gz")
+    with BgzfWriter(p, threads=2) as w:
+        for r in three:
+            w.write_record(*r)
+    assert check_compressed_type(p) == "Bgzip"
+    assert list(iter_fastq(p)) == [(n.decode(), s, q) for n, s, q in three]
+    two = [(b"1", b"ATCG", b"HHHH"), (b"2", b"GCTA", b"MMMM")]
+    with BgzfWriter(p) as w:
+        for r in two:
+            w.write_record(*r)
+    assert gzip.decompress(open(p, "rb").read()) == b"@1\nATCG\n+\nHHHH\n@2\nGCTA\n+\nMMMM\n"
+    # packed path: reader chunk -> writer without per-record objects
+    recs, text = _random_fastq(500, seed=4)
+    src, dst = str(tmp_path / "in.fq"), str(tmp_path / "out.fq.gz")
+    open(src, "wb").write(text)
+    with FastqReader(src) as rd, BgzfWriter(dst, threads=2) as w:
+        for c in rd.chunks(max_reads=64):
+            w.write_chunk(c)
+    assert list(iter_fastq(dst)) == recs
+    assert gzip.decompress(open(dst, "rb").read()) == b"".join(b"@" + n.encode() + b"\n" + s + b"\n+\n" + q + b"\n" for n, s, q in recs)
+
+
+@pytest.mark.parametrize("container", ["plain", "gzip", "bgzf"])
+def test_rank_chunks_cover_every_read_once(tmp_path, container):
+    """The CLI's per-rank reader (host logic of SURVEY 8e): union over ranks == the file, no overlaps;
+    --max-sample keeps exactly the first N records of the file whatever the world size."""
+    from deepchopper_amd.cli import limit_batches, rank_chunks
+
+    recs, text = _random_fastq(700, seed=5, max_len=500)
+    p = str(tmp_path / "r.fq")
+    if container == "plain":
+        open(p, "wb").write(text)
+    elif container == "gzip":
+        open(p, "wb").write(gzip.compress(text, 1))
+    else:
+        with BgzfWriter(p, level=1) as w:
+            w.write(text)
+    names = [r[0] for r in recs]
+    for world in (1, 2, 3, 8):
+        per_rank = [[n for c in rank_chunks(p, r, world, 50, 20_000) for n in c.names()] for r in range(world)]
+        assert sorted(sum(per_rank, [])) == names
+        if container != "gzip":
+            assert sum(per_rank, []) == names  # contiguous shards in rank order
+        for ms in (1, 49, 50, 333, 10_000):
+            got = sorted(n for r in range(world) for c in rank_chunks(p, r, world, 50, 20_000, ms) for n in c.names())
+            assert got == names[:ms]
+    assert len(list(limit_batches(rank_chunks(p, 0, 1, 50, 20_000), 3))) == 3
+    sizes = [c.n for c in rank_chunks(p, 0, 1, 50, 20_000)]
+    assert max(sizes) <= 50 and sum(sizes) == 700

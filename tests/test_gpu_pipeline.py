@@ -180,3 +180,66 @@ def test_chop_driver_matches_oracle(env, tmp_path):
     assert n_chopped > 5, "the test should exercise real chopping"
     assert got == exp
     assert int(os.path.basename(out).split(".")[2].replace("record", "")) == len(got)
+
+
+def test_predict_stream_matches_predict_reads(env, tmp_path):
+    """FASTQ file -> native reader chunks -> predict_stream == predict_reads on the same reads (labels,
+    smoothed labels, intervals, kept segments), for gzip input and ragged chunk sizes."""
+    torch, sd, pipe = env
+    import gzip
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader
+
+    seqs, quals, ids = synth.synth_reads_mixed(90, 100, 3000, seed=11)
+    fq = tmp_path / "mixed.fq.gz"
+    with gzip.open(fq, "wb") as fh:
+        fh.write(synth.to_fastq(seqs, quals, ids))
+    ref, _ = pipe.predict_reads(ids, seqs, quals)
+    got = []
+    with FastqReader(str(fq)) as rd:
+        for res in pipe.predict_stream(rd.chunks(max_reads=16, cap_bases=30_000)):
+            o = res["offsets"]
+            assert len(res["names"]) <= 16 and int(res["lengths"].sum()) <= 30_000
+            for r, name in enumerate(res["names"]):
+                got.append({"id": name, "prediction": res["pred"][o[r]: o[r + 1]], "smooth": res["smooth"][o[r]: o[r + 1]],
+                            "intervals": [tuple(x) for x in res["intervals"][r, : res["n_intervals"][r]].tolist()],
+                            "keep": [tuple(x) for x in res["keep"][r, : res["n_keep"][r]].tolist()]})
+    assert [g["id"] for g in got] == ids
+    for g, e in zip(got, ref):
+        assert np.array_equal(g["prediction"], e["prediction"]) and np.array_equal(g["smooth"], e["smooth"])
+        assert g["intervals"] == e["intervals"] and g["keep"] == e["keep"]
+    # a parse error in the reader thread surfaces in the consumer
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(synth.to_fastq(seqs[:3], quals[:3], ids[:3]) + b"@x\nACGT\n+\nII\n")
+    with FastqReader(str(bad)) as rd, pytest.raises(ValueError, match="length mismatch"):
+        list(pipe.predict_stream(rd.chunks(max_reads=2)))
+
+
+def test_cli_two_ranks_shard_the_file(env, tmp_path):
+    """Two CLI processes with RANK=0/1 (one after the other on this one GPU): byte-range shards of the
+    same FASTQ; the union of their outputs equals the single-rank run (no exchange step)."""
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+    from deepchopper_amd.weights import save_state_dict
+
+    ckpt = tmp_path / "ckpt" / "model.safetensors"
+    save_state_dict(sd, str(ckpt))
+    seqs, quals, ids = synth.synth_reads_mixed(41, 150, 900, seed=12)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(out, rank, world):
+        envv = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        cmd = [sys.executable, "-m", "deepchopper_amd.cli", "predict", str(fq), "-g", str(world), "-o", str(out), "-b", "12",
+               "-m", str(ckpt.parent), "--native", "--no-pt", "--max-reads", "8"]
+        proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300, env=envv)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        return (out / "0" / f"{rank}.intervals.tsv").read_text()
+
+    single = run(tmp_path / "w1", 0, 1)
+    two = run(tmp_path / "w2", 0, 2) + run(tmp_path / "w2", 1, 2)
+    assert [l.split("\t")[0] for l in single.strip().split("\n")] == ids
+    assert two == single
+    assert sorted(os.listdir(tmp_path / "w2" / "0")) == ["0.intervals.tsv", "1.intervals.tsv"]
