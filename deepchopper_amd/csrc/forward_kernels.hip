@@ -17,6 +17,8 @@
 #include "dc_common.h"
 #include "forward.h"
 
+#include <utility>
+
 namespace dc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -291,7 +293,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DC_H_BK 16
 #endif
 #ifndef DC_H_OCC
-#define DC_H_OCC 2
+#define DC_H_OCC 2   // launch bound (waves per SIMD) of gemm6_kernel: the allocator may use up to 256 VGPRs, it needs <= 128
+#endif
+#ifndef DC_HP_OCC
+#define DC_HP_OCC 4  // persistent gemm6p_kernel: capped at 128 VGPRs so that two 8-wave workgroups share a CU
 #endif
 constexpr int H_BK = DC_H_BK;      // k-tile depth
 constexpr int H_OPT = H_BK / 8;    // k-octets per tile
@@ -314,8 +319,11 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 #ifndef DC_H_STAGES
 #define DC_H_STAGES 2
 #endif
+#ifndef DC_H_COMPILER_LDS
+#define DC_H_COMPILER_LDS 0   // 1: leave the fragment reads of the fp16x3 GEMM to the compiler (A/B)
+#endif
 #ifndef DC_H_PERSIST_DEFAULT
-#define DC_H_PERSIST_DEFAULT 3
+#define DC_H_PERSIST_DEFAULT 0
 #endif
 #ifndef DC_H_BN
 #define DC_H_BN 128   // output channels per block
@@ -336,6 +344,41 @@ static_assert(H_NI >= 1 && H_NI * 32 * H_NW == H_BT, "block tile must be covered
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// ---- hand-issued LDS reads ----------------------------------------------------------------------
+// hipcc sinks every LDS fragment read next to its first use and recycles one register quad for all A
+// fragments, so each MFMA group waits out a full LDS round trip.  These wrappers issue the reads as
+// volatile asm (kept in source order, distinct registers) and the matching counted waits by hand;
+// the wait takes the loaded registers as in/out operands so that no consumer can be moved above it.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int O0, int O1>  // two dwords at addr + 256 * O0 and addr + 256 * O1
+__device__ __forceinline__ f32x2 lds_read2st64(uint32_t addr) {
+  f32x2 v;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int MODE>
 struct SplitMode;
 
@@ -348,6 +391,7 @@ struct SplitMode<0> {
     split3(x, o[0], o[1], o[2]);
     return false;  // bf16 has the fp32 exponent range: nothing can overflow
   }
+  static __device__ __forceinline__ void split_mx(const float (&x)[8], vec (&o)[3], float&) { split3(x, o[0], o[1], o[2]); }
   static __device__ __forceinline__ f32x16 mma(const vec (&a)[3], const vec (&b)[3], f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);  // small terms first
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
@@ -370,6 +414,16 @@ struct SplitMode<1> {
   static constexpr int NP = 2;
   static __device__ __forceinline__ bool split(const float (&x)[8], vec (&o)[2]) {
     bool ovf = false;
+#ifdef DC_ABL_NOSPLIT
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 v = {x[j], x[j + 1]};
+      const f16x2 hp = __builtin_convertvector(v, f16x2);
+      o[0][j] = hp[0]; o[0][j + 1] = hp[1];
+    }
+    o[1] = o[0];
+    return false;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       ovf = ovf || !(fabsf(x[j]) <= 65504.f) || !(fabsf(x[j + 1]) <= 65504.f);  // also catches NaN
@@ -381,6 +435,21 @@ struct SplitMode<1> {
       o[1][j] = lp[0]; o[1][j + 1] = lp[1];
     }
     return ovf;
+  }
+  // GEMM hot loop form: the range guard is a running max of |x| (one v_max3 per pair, tested once per
+  // workgroup at the end) instead of two compares per element.  NaN does not raise it: a NaN operand
+  // yields NaN logits in every mode, which is what the fp32 reference does too.
+  static __device__ __forceinline__ void split_mx(const float (&x)[8], vec (&o)[2], float& mx) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      mx = fmaxf(fmaxf(fabsf(x[j]), fabsf(x[j + 1])), mx);
+      const f32x2 v = {x[j], x[j + 1]};
+      const f16x2 hp = __builtin_convertvector(v, f16x2);
+      const f32x2 r = {__builtin_fmaf((float)hp[0], -1.0f, x[j]), __builtin_fmaf((float)hp[1], -1.0f, x[j + 1])};
+      const f16x2 lp = __builtin_convertvector(r, f16x2);
+      o[0][j] = hp[0]; o[0][j + 1] = hp[1];
+      o[1][j] = lp[0]; o[1][j + 1] = lp[1];
+    }
   }
   static __device__ __forceinline__ f32x16 mma(const vec (&a)[2], const vec (&b)[2], f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
@@ -520,7 +589,43 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   // per-lane position inside one B instruction (256 consecutive floats of the row-major [k][H_BT] tile)
   const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
   constexpr int B_ROWS_PER_INSTR = 256 / H_BT > 0 ? 256 / H_BT : 1;
+  // Every wave owns fixed LDS-DMA slots of the k-tile image (slot q = wave + it * H_NW), so its source
+  // pointers are set up once and only stepped per k-tile: no address arithmetic or branches in the loop.
+  constexpr bool FAST = (A_INSTR % H_NW == 0) && (B_INSTR % H_NW == 0) && (H_BT >= 256);
+  constexpr int A_PER = FAST ? A_INSTR / H_NW : 1, B_PER = FAST ? B_INSTR / H_NW : 1;
+  const unsigned short* a_src[A_PER];
+  const float* b_src[B_PER];
+  uint32_t a_dst[A_PER], b_dst[B_PER];
+  if (FAST) {
+#pragma unroll
+    for (int it = 0; it < A_PER; ++it) {
+      const int q = wave + it * H_NW;
+      const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
+      a_src[it] = g.Wp + ((((int64_t)pl * K8 + o) * g.N + n_blk + seg * 64 + lane) << 3);
+      a_dst[it] = lds0 + ((pl * H_OPT + o) * H_BN + seg * 64) * 16;
+    }
+#pragma unroll
+    for (int it = 0; it < B_PER; ++it) {
+      const int bq = wave + it * H_NW;
+      b_src[it] = g.X + (int64_t)((bq * 256) / H_BT) * g.Tp + t_blk + (bq * 256) % H_BT + lane * 4;
+      b_dst[it] = lds0 + H_A_BYTES + bq * 1024;
+    }
+  }
+  const int64_t a_step = (int64_t)H_OPT * g.N * 8, b_step = (int64_t)H_BK * g.Tp;
   auto stage = [&](int buf, int kt) {
+    if (FAST) {  // called with kt = 0, 1, 2, ... in order: the pointers walk along k
+#pragma unroll
+      for (int it = 0; it < A_PER; ++it) {
+        glds16(reinterpret_cast<const float*>(a_src[it]), a_dst[it] + buf * BUF);
+        a_src[it] += a_step;
+      }
+#pragma unroll
+      for (int it = 0; it < B_PER; ++it) {
+        glds16(b_src[it], b_dst[it] + buf * BUF);
+        b_src[it] += b_step;
+      }
+      return;
+    }
     for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
       if (q < A_INSTR) {
         const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
@@ -538,7 +643,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   };
 
   const int nk = g.K / H_BK;  // >= 16 for every GEMM of this model, so the ring always fills
-  bool ovf = false;           // fp16x3: an activation left the fp16 range
+  float mx = 0.f;             // fp16x3 range guard: running max |activation| (SplitMode<1>::split_mx)
 #pragma unroll
   for (int st = 0; st < S - 1; ++st) stage(st, st);
 
@@ -584,30 +689,75 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     const unsigned char* bufp = smem6 + cur * BUF;
     const svec* pA = reinterpret_cast<const svec*>(bufp);
     const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
-#pragma unroll
-    for (int s = 0; s < H_BK / 16; ++s) {
-      svec bs[H_NI][SM::NP];
-#pragma unroll
-      for (int ni = 0; ni < H_NI; ++ni) {
+    static_for<H_BK / 16>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (MODE == 1 && H_NI == 1 && H_BT == 256 && !DC_H_COMPILER_LDS) {
+        // all 4 + 2 * H_MI reads of the step in flight at once (lgkmcnt counts up to 15)
+        static_assert(4 + 2 * H_MI <= 15, "too many LDS reads in flight");
+        const uint32_t aA = lds0 + cur * BUF + (h * H_BN + i) * 16;
+        const uint32_t aB = lds0 + cur * BUF + H_A_BYTES + (8 * h * H_BT + t_w + i) * 4;
+        f32x2 xb[4];
+        u32x4 afr[H_MI][2];
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          xb[j] = lds_read2st64<4 * (16 * s + 2 * j), 4 * (16 * s + 2 * j + 1)>(aB);
+        });
+        static_for<H_MI>([&](auto mc) {
+          constexpr int mi = decltype(mc)::value;
+          afr[mi][0] = lds_read_b128<((0 * H_OPT + 2 * s) * H_BN + mi * 32) * 16>(aA);
+          afr[mi][1] = lds_read_b128<((1 * H_OPT + 2 * s) * H_BN + mi * 32) * 16>(aA);
+        });
+        lds_wait<2 * H_MI>(xb[0], xb[1], xb[2], xb[3]);
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
-          x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
+        for (int j = 0; j < 4; ++j) {
+          x[2 * j] = LN ? fmaf(xb[j][0], rs[0], nm[0]) : xb[j][0];
+          x[2 * j + 1] = LN ? fmaf(xb[j][1], rs[0], nm[0]) : xb[j][1];
         }
-        ovf |= SM::split(x, bs[ni]);
-      }
+        svec bs[2];
+        SM::split_mx(x, bs, mx);
+        static_for<H_MI>([&](auto mc) {
+          constexpr int mi = decltype(mc)::value;
+          lds_wait<2 * (H_MI - 1 - mi)>(afr[mi][0], afr[mi][1]);
+          const svec af[2] = {__builtin_bit_cast(svec, afr[mi][0]), __builtin_bit_cast(svec, afr[mi][1])};
+          acc[mi][0] = SM::mma(af, bs, acc[mi][0]);
+        });
+      } else {
+      // issue every LDS read of the s-step up front (B first: the split needs it first), so the LDS
+        // latency is paid once per step instead of once per fragment
+        float xr[H_NI][8];
 #pragma unroll
-      for (int mi = 0; mi < H_MI; ++mi) {
-        svec af[SM::NP];
+        for (int ni = 0; ni < H_NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < SM::NP; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
+          for (int j = 0; j < 8; ++j) xr[ni][j] = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
+        svec af[H_MI][SM::NP];
+#pragma unroll
+        for (int mi = 0; mi < H_MI; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < SM::NP; ++pl) af[mi][pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
+        svec bs[H_NI][SM::NP];
 #pragma unroll
         for (int ni = 0; ni < H_NI; ++ni) {
-          acc[mi][ni] = SM::mma(af, bs[ni], acc[mi][ni]);
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#ifdef DC_ABL_NOSPLIT
+            x[j] = xr[ni][j];
+#else
+            x[j] = LN ? fmaf(xr[ni][j], rs[ni], nm[ni]) : xr[ni][j];
+#endif
+          }
+          SM::split_mx(x, bs[ni], mx);
         }
-      }
+#pragma unroll
+        for (int mi = 0; mi < H_MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < H_NI; ++ni) {
+            acc[mi][ni] = SM::mma(af[mi], bs[ni], acc[mi][ni]);
+          }
+        }
     }
+      });
     // next iteration reads tile kt+1: it has landed when only the tiles younger than it are outstanding
     if (kt + S - 1 < nk) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
@@ -617,7 +767,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     __syncthreads();
     cur = cur + 1 == S ? 0 : cur + 1;
   }
-  if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(g.overflow, 1);
+  if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
 #ifdef DC_H_DIRECT_EPI
   gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
 #else
@@ -630,7 +780,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 // so the LDS-DMA stream never drains at tile boundaries (no exposed prologue latency per tile).
 // Tiles are dealt per XCD (n fastest) so the blocks of one XCD work on the same token panels.
 template <int EPI, bool LN, int MODE>
-__global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * DC_H_NW, DC_HP_OCC) void gemm6p_kernel(GemmArgs g) {
   typedef SplitMode<MODE> SM;
   typedef typename SM::vec svec;
   constexpr int H_A_BYTES = SM::NP * H_BK * H_BN * 2;
@@ -657,30 +807,82 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
   const int K8 = g.K >> 3;
   const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
   constexpr int B_ROWS_PER_INSTR = 256 / H_BT > 0 ? 256 / H_BT : 1;
-  auto stage = [&](int buf, int n_blk, int64_t t_blk, int kt) {
+  // fixed LDS-DMA slots per wave, source pointers stepped along k (see gemm6_kernel); set_tile() re-bases
+  // them when the workgroup moves to its next output tile
+  constexpr bool FAST = (A_INSTR % H_NW == 0) && (B_INSTR % H_NW == 0) && (H_BT >= 256);
+  constexpr int A_PER = FAST ? A_INSTR / H_NW : 1, B_PER = FAST ? B_INSTR / H_NW : 1;
+  const unsigned short* a_src[A_PER];
+  const float* b_src[B_PER];
+  uint32_t a_dst[A_PER], b_dst[B_PER];
+  int kt_next = 0, n_cur = 0;
+  int64_t t_cur = 0;
+  const int64_t a_step = (int64_t)H_OPT * g.N * 8, b_step = (int64_t)H_BK * g.Tp;
+  if (FAST) {
+#pragma unroll
+    for (int it = 0; it < A_PER; ++it) {
+      const int q = wave + it * H_NW;
+      a_dst[it] = lds0 + (((q / (A_SEG * H_OPT)) * H_OPT + (q / A_SEG) % H_OPT) * H_BN + (q % A_SEG) * 64) * 16;
+    }
+#pragma unroll
+    for (int it = 0; it < B_PER; ++it) b_dst[it] = lds0 + H_A_BYTES + (wave + it * H_NW) * 1024;
+  }
+  auto set_tile = [&](int n_blk, int64_t t_blk) {
+    n_cur = n_blk;
+    t_cur = t_blk;
+    kt_next = 0;
+    if (FAST) {
+#pragma unroll
+      for (int it = 0; it < A_PER; ++it) {
+        const int q = wave + it * H_NW;
+        const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
+        a_src[it] = g.Wp + ((((int64_t)pl * K8 + o) * g.N + n_blk + seg * 64 + lane) << 3);
+      }
+#pragma unroll
+      for (int it = 0; it < B_PER; ++it) {
+        const int bq = wave + it * H_NW;
+        b_src[it] = g.X + (int64_t)((bq * 256) / H_BT) * g.Tp + t_blk + (bq * 256) % H_BT + lane * 4;
+      }
+    }
+  };
+  auto stage = [&](int buf) {  // next k-tile of the tile given to set_tile()
+    if (FAST) {
+#pragma unroll
+      for (int it = 0; it < A_PER; ++it) {
+        glds16(reinterpret_cast<const float*>(a_src[it]), a_dst[it] + buf * BUF);
+        a_src[it] += a_step;
+      }
+#pragma unroll
+      for (int it = 0; it < B_PER; ++it) {
+        glds16(b_src[it], b_dst[it] + buf * BUF);
+        b_src[it] += b_step;
+      }
+      return;
+    }
+    const int kt = kt_next++;
     for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
       if (q < A_INSTR) {
         const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
         const unsigned short* src =
-            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_blk + seg * 64 + lane) << 3);
+            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_cur + seg * 64 + lane) << 3);
         glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * H_BN + seg * 64) * 16);
       } else {
         const int bq = q - A_INSTR;
         const int row = (H_BT >= 256) ? (bq * 256) / H_BT : bq * B_ROWS_PER_INSTR + b_row_l;
         const int col = (H_BT >= 256) ? (bq * 256) % H_BT + lane * 4 : b_col_l;
-        const float* src = g.X + ((int64_t)kt * H_BK + row) * g.Tp + t_blk + col;
+        const float* src = g.X + ((int64_t)kt * H_BK + row) * g.Tp + t_cur + col;
         glds16(src, lds0 + buf * BUF + H_A_BYTES + bq * 1024);
       }
     }
   };
   const int nk = g.K / H_BK;
   if (jb >= x_n) return;  // block-uniform: fewer tiles than blocks on this XCD
-  bool ovf = false;       // fp16x3: an activation left the fp16 range
+  float mx = 0.f;         // fp16x3 range guard: running max |activation| (SplitMode<1>::split_mx)
 
   unsigned loc = jb;
   int n_blk = (int)((x_lo + loc) % n_blocks) * H_BN;
   int64_t t_blk = (int64_t)((x_lo + loc) / n_blocks) * H_BT;
-  stage(0, n_blk, t_blk, 0);
+  set_tile(n_blk, t_blk);
+  stage(0);
   int cur = 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -717,8 +919,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) stage(cur ^ 1, n_blk, t_blk, kt + 1);
-      else if (has_next) stage(cur ^ 1, n_next, t_next, 0);  // first k-tile of the next output tile
+      if (kt + 1 < nk) stage(cur ^ 1);
+      else if (has_next) {  // first k-tile of the next output tile
+        set_tile(n_next, t_next);
+        stage(cur ^ 1);
+      }
       const unsigned char* bufp = smem6 + cur * BUF;
       const svec* pA = reinterpret_cast<const svec*>(bufp);
       const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
@@ -733,7 +938,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
             const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
             x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
           }
-          ovf |= SM::split(x, bs[ni]);
+          SM::split_mx(x, bs[ni], mx);
         }
 #pragma unroll
         for (int mi = 0; mi < H_MI; ++mi) {
@@ -757,7 +962,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6p_kernel(GemmArgs
     n_blk = n_next;
     t_blk = t_next;
   }
-  if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(g.overflow, 1);
+  if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
 }
 
 template <int EPI, bool LN>
@@ -771,7 +976,8 @@ static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
     // 3 = measured best per epilogue: persistent (direct epilogue) except for the GELU and fused-head epilogues
     if ((persist == 1 && g.K <= 256) || persist == 2 ||
         (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) || EPI == EPI_BIAS_RES_STATS) {
-      unsigned gp = 256u * DC_H_OCC;  // one wave of workgroups: occupancy x 256 CUs (multiple of 8)
+      // one wave of workgroups: (DC_HP_OCC waves per SIMD x 4 SIMDs / waves per workgroup) x 256 CUs
+      unsigned gp = 256u * (unsigned)((DC_HP_OCC * 4 / H_NW) > 0 ? (DC_HP_OCC * 4 / H_NW) : 1);
       if (gp > grid6) gp = (grid6 + 7u) & ~7u;
       if (g.split_mode == 1)
         hipLaunchKernelGGL((gemm6p_kernel<EPI, LN, 1>), dim3(gp), dim3(64 * H_NW), 0, st, g);
