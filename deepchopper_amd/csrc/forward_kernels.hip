@@ -317,7 +317,10 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 }
 
 #ifndef DC_H_STAGES
-#define DC_H_STAGES 2
+#define DC_H_STAGES 3
+#endif
+#ifndef DC_H_DMA_INTERLEAVE
+#define DC_H_DMA_INTERLEAVE 1  // 1: issue the next k-tile's LDS-DMA slots between the MFMA groups (A/B)
 #endif
 #ifndef DC_H_COMPILER_LDS
 #define DC_H_COMPILER_LDS 0   // 1: leave the fragment reads of the fp16x3 GEMM to the compiler (A/B)
@@ -445,7 +448,11 @@ struct SplitMode<1> {
       mx = fmaxf(fmaxf(fabsf(x[j]), fabsf(x[j + 1])), mx);
       const f32x2 v = {x[j], x[j + 1]};
       const f16x2 hp = __builtin_convertvector(v, f16x2);
-      const f32x2 r = {__builtin_fmaf((float)hp[0], -1.0f, x[j]), __builtin_fmaf((float)hp[1], -1.0f, x[j + 1])};
+      // r = x - float(h) in one mixed-precision FMA per element (exact: the difference of two fp32-representable
+      // numbers this close is representable); hipcc would emit v_cvt_f32_f16 + v_sub for it
+      f32x2 r;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hp), "v"(x[j]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hp), "v"(x[j + 1]));
       const f16x2 lp = __builtin_convertvector(r, f16x2);
       o[0][j] = hp[0]; o[0][j + 1] = hp[1];
       o[1][j] = lp[0]; o[1][j + 1] = lp[1];
@@ -617,12 +624,16 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 #pragma unroll
       for (int it = 0; it < A_PER; ++it) {
         glds16(reinterpret_cast<const float*>(a_src[it]), a_dst[it] + buf * BUF);
+#ifndef DC_ABL_SAMEK_A
         a_src[it] += a_step;
+#endif
       }
 #pragma unroll
       for (int it = 0; it < B_PER; ++it) {
         glds16(b_src[it], b_dst[it] + buf * BUF);
+#ifndef DC_ABL_SAMEK_B
         b_src[it] += b_step;
+#endif
       }
       return;
     }
@@ -641,6 +652,21 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
       }
     }
   };
+
+  // one LDS-DMA slot of the next k-tile (slots 0 .. A_PER + B_PER - 1): lets the k-loop spread the issue
+  // cost of the DMA instructions between its MFMA groups instead of paying it up front
+  auto stage_slot = [&](int buf, auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < A_PER) {
+      glds16(reinterpret_cast<const float*>(a_src[q]), a_dst[q] + buf * BUF);
+      a_src[q] += a_step;
+    } else {
+      glds16(b_src[q - A_PER], b_dst[q - A_PER] + buf * BUF);
+      b_src[q - A_PER] += b_step;
+    }
+  };
+  constexpr bool ILV = DC_H_DMA_INTERLEAVE && FAST && MODE == 1 && H_NI == 1 && H_BT == 256 && H_BK == 16 &&
+                       (A_PER + B_PER <= H_MI) && !DC_H_COMPILER_LDS;
 
   const int nk = g.K / H_BK;  // >= 16 for every GEMM of this model, so the ring always fills
   float mx = 0.f;             // fp16x3 range guard: running max |activation| (SplitMode<1>::split_mx)
@@ -679,12 +705,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
+    const bool do_stage = kt + S - 1 < nk;
+    int nxt = cur + S - 1;
+    if (nxt >= S) nxt -= S;
 #ifndef DC_ABL_NOLOAD
-    if (kt + S - 1 < nk) {
-      int nxt = cur + S - 1;
-      if (nxt >= S) nxt -= S;
-      stage(nxt, kt + S - 1);  // overwrites the buffer consumed in iteration kt-1 (all waves passed its barrier)
-    }
+    if (!ILV && do_stage) stage(nxt, kt + S - 1);  // overwrites the buffer consumed in iteration kt-1 (all waves passed its barrier)
 #endif
     const unsigned char* bufp = smem6 + cur * BUF;
     const svec* pA = reinterpret_cast<const svec*>(bufp);
@@ -721,6 +746,11 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
           lds_wait<2 * (H_MI - 1 - mi)>(afr[mi][0], afr[mi][1]);
           const svec af[2] = {__builtin_bit_cast(svec, afr[mi][0]), __builtin_bit_cast(svec, afr[mi][1])};
           acc[mi][0] = SM::mma(af, bs, acc[mi][0]);
+          if constexpr (ILV && mi < A_PER + B_PER) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_stage) stage_slot(nxt, mc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
       } else {
       // issue every LDS read of the s-step up front (B first: the split needs it first), so the LDS
@@ -759,12 +789,16 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     }
       });
     // next iteration reads tile kt+1: it has landed when only the tiles younger than it are outstanding
-    if (kt + S - 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
+#ifndef DC_ABL_NOVMWAIT
+    if (S == 2 || kt + S - 1 >= nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S > 2: ring draining, at most S-2 short iterations
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ring draining: at most S-2 short iterations
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
     }
+#endif
+#ifndef DC_ABL_NOBARRIER
     __syncthreads();
+#endif
     cur = cur + 1 == S ? 0 : cur + 1;
   }
   if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
