@@ -325,6 +325,9 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 #ifndef DC_H_COMPILER_LDS
 #define DC_H_COMPILER_LDS 0   // 1: leave the fragment reads of the fp16x3 GEMM to the compiler (A/B)
 #endif
+#ifndef DC_H_PERSIST_STATS
+#define DC_H_PERSIST_STATS 0   // 1: out_proj / fc2 (statistics epilogue) through the persistent kernel
+#endif
 #ifndef DC_H_PERSIST_DEFAULT
 #define DC_H_PERSIST_DEFAULT 0
 #endif
@@ -370,8 +373,16 @@ __device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+// c += a * b on v_mfma_f32_32x32x16_f16, accumulating in place (tied operand)
+__device__ __forceinline__ void mfma_f16_inplace(f32x16& c, const u32x4& a, const u32x4& b) {
+  asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -515,6 +526,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
         for (int c = 0; c < 4; ++c) {
           float x = o[c];
           if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS) x += r4[c];
+          if (EPI == EPI_BIAS_RES_STATS) {  // LayerNorm statistics of the new residual stream (next GEMM's LN)
+            s0[c] += x;
+            s1[c] = fmaf(x, x, s1[c]);
+          }
           if (EPI == EPI_BIAS_GELU) x = g.gelu_tanh ? gelu_tanh(x) : gelu_erf(x);
           if (EPI == EPI_BIAS_RELU_Q) x = fmaxf(x, 0.f) + q4[c];       // head.py:94,97
           if (EPI == EPI_BIAS_RES_RELU || EPI == EPI_HEAD2_FUSED) x = fmaxf(x + r4[c], 0.f);  // head.py:98
@@ -532,6 +547,23 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 #endif
         }
         (void)n;
+      }
+    }
+    if (EPI == EPI_BIAS_RES_STATS) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int d = 8; d <= 32; d <<= 1) {
+          s0[c] += __shfl_xor(s0[c], d, 64);
+          s1[c] += __shfl_xor(s1[c], d, 64);
+        }
+      }
+      if (rr == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          atomicAdd(g.st_sum + t + c, s0[c]);  // N / block height = 2 addends per token: order-independent
+          atomicAdd(g.st_sq + t + c, s1[c]);
+        }
       }
     }
     if (EPI == EPI_HEAD2_FUSED) {
@@ -554,6 +586,17 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   }
 }
 
+#ifdef DC_STAMP
+// Diagnostic build only (never the shipped library): per epilogue kind, wave-summed shader cycles spent in
+// the prologue, the k-loop and the epilogue of gemm6_kernel, plus the number of waves.  Read with
+// dc_debug_read_stamps() (tools/ab_run.sh prints it when the symbol exists).
+__device__ unsigned long long dc_stamps[8][4];
+__device__ unsigned long long dc_stamps_rt[8];  // wave-summed s_memrealtime (100 MHz) ticks, whole kernel
+#define DC_STAMP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define DC_STAMP_T(var)
+#endif
+
 template <int EPI, bool LN, int MODE>
 __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs g) {
   typedef SplitMode<MODE> SM;
@@ -565,6 +608,10 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   constexpr int SMEM = (S * BUF > EPI_BYTES) ? S * BUF : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem6[SMEM];
 
+  DC_STAMP_T(st0);
+#ifdef DC_STAMP
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const unsigned nwg = gridDim.x;
   unsigned bid = blockIdx.x;
   {
@@ -703,6 +750,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
   __syncthreads();
 
+  DC_STAMP_T(st1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const bool do_stage = kt + S - 1 < nk;
@@ -802,10 +850,27 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     cur = cur + 1 == S ? 0 : cur + 1;
   }
   if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
+  DC_STAMP_T(st2);
 #ifdef DC_H_DIRECT_EPI
   gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
 #else
+#ifdef DC_ABL_SKIPEPI
+#pragma unroll
+  for (int a = 0; a < H_MI; ++a) asm volatile("" ::"v"(acc[a][0]));
+#else
   gemm_epilogue_lds<EPI, H_MI, H_NI>(g, acc, reinterpret_cast<float*>(smem6) + wave * 1024, n_blk, t_blk + t_w, lane);
+#endif
+#endif
+#ifdef DC_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left the wave
+  DC_STAMP_T(st3);
+  if (lane == 0) {
+    atomicAdd(&dc_stamps[EPI][0], st1 - st0);
+    atomicAdd(&dc_stamps[EPI][1], st2 - st1);
+    atomicAdd(&dc_stamps[EPI][2], st3 - st2);
+    atomicAdd(&dc_stamps[EPI][3], 1ull);
+    atomicAdd(&dc_stamps_rt[EPI], __builtin_amdgcn_s_memrealtime() - rt0);
+  }
 #endif
 }
 
@@ -1008,8 +1073,10 @@ static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
     static const int persist = getenv("DC_GEMM_PERSIST") ? atoi(getenv("DC_GEMM_PERSIST")) : DC_H_PERSIST_DEFAULT;
     // persist: 0 = one tile per workgroup, 1 = persistent for K <= 256, 2 = persistent for every GEMM,
     // 3 = measured best per epilogue: persistent (direct epilogue) except for the GELU and fused-head epilogues
+    static const int persist_stats = getenv("DC_GEMM_PERSIST_STATS") ? atoi(getenv("DC_GEMM_PERSIST_STATS")) : DC_H_PERSIST_STATS;
     if ((persist == 1 && g.K <= 256) || persist == 2 ||
-        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) || EPI == EPI_BIAS_RES_STATS) {
+        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) ||
+        (EPI == EPI_BIAS_RES_STATS && persist_stats)) {
       // one wave of workgroups: (DC_HP_OCC waves per SIMD x 4 SIMDs / waves per workgroup) x 256 CUs
       unsigned gp = 256u * (unsigned)((DC_HP_OCC * 4 / H_NW) > 0 ? (DC_HP_OCC * 4 / H_NW) : 1);
       if (gp > grid6) gp = (grid6 + 7u) & ~7u;
@@ -1936,3 +2003,14 @@ int launch_head_out(hipStream_t st, const float* o, const float* w3, const float
 }
 
 }  // namespace dc
+
+#ifdef DC_STAMP
+// diagnostic builds only: copy out and clear the cycle stamps (8 epilogue kinds x {prologue, loop, epilogue, waves}, then 8 x realtime ticks): out[40]
+extern "C" int dc_debug_read_stamps(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::dc_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(dc::dc_stamps_rt), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+  unsigned long long zero[32] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dc::dc_stamps_rt), zero, sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(dc::dc_stamps), zero, sizeof zero) == hipSuccess ? 0 : 1;
+}
+#endif
