@@ -30,6 +30,7 @@ FLOPS_PER_TOKEN = {
     "gemm_outproj": 2 * 256 * 256,
     "gemm_fc1": 2 * 256 * 1024,
     "gemm_fc2": 2 * 1024 * 256,
+    "mlp_fused": 2 * 256 * 1024 + 2 * 1024 * 256,
     "gemm_head1": 2 * 256 * 1024,
     "gemm_head2": 2 * 1024 * 1024,
 }

@@ -40,6 +40,12 @@ struct GemmArgs {
   int K, N;
   int64_t Tp;
   int gelu_tanh;
+  // fused MLP (launch_mlp_fused): second matrix = fc2, split planes with the k order permuted inside every
+  // aligned group of 16 hidden units so that fc1's accumulator registers are fc2's B fragments as they stand
+  const unsigned short* Wp2;  // [2][N/8][K][8] fp16 h|l of fc2^T * w_scale2 (N hidden -> K outputs)
+  const float* bias2;         // [K]
+  float w_inv_scale2;
+  int stats_store;            // EPI_BIAS_RES_STATS: 1 = this workgroup owns all channels of its tokens: plain stores
 };
 
 struct FilterArgs {
@@ -77,6 +83,11 @@ struct HyenaArgs {
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
+// x <- x + fc2(gelu(fc1(LN(x)))) in one kernel (fp16x3 only): g.Wp / bias / w_inv_scale = fc1 (K = D -> N = d_inner),
+// g.Wp2 / bias2 / w_inv_scale2 = fc2 (permuted planes), X = R = C = the residual stream, mean / rstd = sum / sum of
+// squares in, st_sum / st_sq = the new statistics out (same buffers, overwritten)
+int launch_mlp_fused(hipStream_t st, const GemmArgs& g);
+int mlp_fused_perm16(int kappa);  // hidden unit (within an aligned 16-group) that logical k index kappa stands for
 int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (partials of EPI_HEAD2_FUSED)
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);

@@ -25,6 +25,7 @@ struct LayerDev {
   float *Wt_fc2 = nullptr, *b_fc2 = nullptr;  // [DI][D], [D]
   unsigned short *Wp_in = nullptr, *Wp_out = nullptr, *Wp_fc1 = nullptr, *Wp_fc2 = nullptr;  // bf16 planes
   unsigned short *Wq_in = nullptr, *Wq_out = nullptr, *Wq_fc1 = nullptr, *Wq_fc2 = nullptr;  // fp16 planes (scaled)
+  unsigned short* Wq_fc2p = nullptr;  // fc2 planes with the k order of the fused MLP kernel (mlp_fused_perm16)
   float is_in = 1.f, is_out = 1.f, is_fc1 = 1.f, is_fc2 = 1.f;                              // 1 / weight scale
   // implicit filter parameters (device copies, checkpoint layout)
   float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
@@ -569,13 +570,43 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    if ((rc = run_gemm(m, st, "gemm_fc1", WRef{L.Wt_fc1, L.Wp_fc1, L.Wq_fc1, L.is_fc1}, x, hm, L.b_fc1, nullptr, nullptr, true, EPI_BIAS_GELU, D,
-                       DI, sums)))
-      return rc;
-    if (sums && (rc = zero_stats())) return rc;
-    if ((rc = run_gemm(m, st, "gemm_fc2", WRef{L.Wt_fc2, L.Wp_fc2, L.Wq_fc2, L.is_fc2}, hm, x, L.b_fc2, x, nullptr, false,
-                       sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, DI, D)))
-      return rc;
+    static const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
+    if (m->gemm_mode == 2 && sums && !no_mlp_fuse && L.Wq_fc2p && D == 256 && DI % 128 == 0 && DI <= 1024) {
+      // fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide activation stays
+      // in registers (fp16x3 only)
+      GemmArgs g{};
+      g.Wp = L.Wq_fc1;
+      g.Wp2 = L.Wq_fc2p;
+      g.split_mode = 1;
+      g.w_inv_scale = L.is_fc1;
+      g.w_inv_scale2 = L.is_fc2;
+      g.bias = L.b_fc1;
+      g.bias2 = L.b_fc2;
+      g.overflow = m->d_overflow;
+      g.X = x;
+      g.R = x;
+      g.C = x;
+      g.mean = mean;
+      g.rstd = rstd;
+      g.st_sum = mean;
+      g.st_sq = rstd;
+      g.stats_are_sums = 1;
+      g.ln_eps = c.ln_eps;
+      g.K = D;
+      g.N = DI;
+      g.Tp = Tp;
+      g.gelu_tanh = c.gelu_tanh;
+      ProfScope ps(m, st, "mlp_fused");
+      if ((rc = launch_mlp_fused(st, g))) return rc;
+    } else {
+      if ((rc = run_gemm(m, st, "gemm_fc1", WRef{L.Wt_fc1, L.Wp_fc1, L.Wq_fc1, L.is_fc1}, x, hm, L.b_fc1, nullptr, nullptr, true,
+                         EPI_BIAS_GELU, D, DI, sums)))
+        return rc;
+      if (sums && (rc = zero_stats())) return rc;
+      if ((rc = run_gemm(m, st, "gemm_fc2", WRef{L.Wt_fc2, L.Wp_fc2, L.Wq_fc2, L.is_fc2}, hm, x, L.b_fc2, x, nullptr, false,
+                         sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, DI, D)))
+        return rc;
+    }
   }
   const bool head_sums = fused_stats && l0_table;
   if (!head_sums) {
@@ -691,6 +722,13 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     UP(upload(m, Wt, &L.Wt_fc2));
     UP(upload_planes(m, Wt, DI, D, &L.Wp_fc2));
     UP(upload_planes_f16(m, Wt, DI, D, &L.Wq_fc2, &L.is_fc2));
+    if (DI % 16 == 0) {  // fused MLP: logical k index 16 b + kappa stands for hidden unit 16 b + perm16(kappa)
+      std::vector<float> Wtp((size_t)DI * D);
+      for (int k = 0; k < DI; ++k)
+        memcpy(&Wtp[(size_t)k * D], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * D], (size_t)D * sizeof(float));
+      float is_p = 0.f;
+      UP(upload_planes_f16(m, Wtp, DI, D, &L.Wq_fc2p, &is_p));  // same values, same power-of-two scale as Wq_fc2
+    }
     UP(upload(m, bo, &L.b_fc2));
     UP(upload_raw(m, lw.pos_z, (size_t)cfg->max_seq_len * emb, &L.pos_z));
     UP(upload_raw(m, lw.pos_t, (size_t)cfg->max_seq_len, &L.pos_t));

@@ -62,6 +62,16 @@ __device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: one VGPR of addressing
+// instead of a 64-bit pointer pair per stream
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
 
 // Epilogue shared by the fp32 and the bf16x6 GEMM kernels: C[n][t], n = accumulator row, t = lane
@@ -482,12 +492,11 @@ struct SplitMode<1> {
 // tile).  Each wave bounces its 32x32 tiles through a private 4 KiB LDS patch and reads them back
 // row-wise, so residual loads and result stores are 16 B per lane and every wave instruction moves
 // eight full 128-byte lines.
-template <int EPI, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][NI], float* patch, int n_w0,
-                                                  int64_t t_w0, int lane) {
+template <int EPI, int MI, int NI, class PatchWriter>
+__device__ __forceinline__ void gemm_epilogue_lds_core(const GemmArgs& g, PatchWriter write_patch, float* patch, int n_w0,
+                                                       int64_t t_w0, int lane) {
   constexpr bool RES = (EPI == EPI_BIAS_RES) || (EPI == EPI_BIAS_RES_RELU) || (EPI == EPI_HEAD2_FUSED) ||
                        (EPI == EPI_BIAS_RES_STATS);
-  const int i = lane & 31, h = lane >> 5;
   const int rr = lane >> 3, c4 = (lane & 7) * 4;  // read-back: row rr (+8 per pass), 4 tokens at column c4
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -497,8 +506,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};  // partial logits (EPI_HEAD2_FUSED)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[mi][ni][e];
+      write_patch(mi, ni, patch);  // the 32 x 32 (channel x token) tile (mi, ni), row-major
       // same wave writes and reads the patch: LDS operations of one wave complete in order
       float4 v[4], rv[4];
       float bias[4], w30[4], w31[4];
@@ -559,10 +567,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
         }
       }
       if (rr == 0) {
+        if (g.stats_store) {  // this workgroup holds every channel of its tokens (fused MLP)
+          *reinterpret_cast<float4*>(g.st_sum + t) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+          *reinterpret_cast<float4*>(g.st_sq + t) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          atomicAdd(g.st_sum + t + c, s0[c]);  // N / block height = 2 addends per token: order-independent
-          atomicAdd(g.st_sq + t + c, s1[c]);
+          for (int c = 0; c < 4; ++c) {
+            atomicAdd(g.st_sum + t + c, s0[c]);  // N / block height = 2 addends per token: order-independent
+            atomicAdd(g.st_sq + t + c, s1[c]);
+          }
         }
       }
     }
@@ -584,6 +597,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
       }
     }
   }
+}
+
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[MI][NI], float* patch, int n_w0,
+                                                  int64_t t_w0, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+  gemm_epilogue_lds_core<EPI, MI, NI>(
+      g,
+      [&](int mi, int ni, float* p) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) p[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + i] = acc[mi][ni][e];
+      },
+      patch, n_w0, t_w0, lane);
 }
 
 #ifdef DC_STAMP
@@ -872,6 +898,262 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     atomicAdd(&dc_stamps_rt[EPI], __builtin_amdgcn_s_memrealtime() - rt0);
   }
 #endif
+}
+
+// =====================================================================================
+// Fused MLP (fp16x3): x <- x + fc2(gelu(fc1(LN(x)))) with the d_inner-wide activation kept in registers.
+//
+// A workgroup owns 256 tokens (8 waves x 32) and ALL channels.  For each chunk of 128 hidden units it runs
+//   16 "type-1" steps: fc1 k-tiles (X k-tile 16 x 256 fp32 + W1 tile 128 x 16 as fp16 h|l planes) -> acc1[4]
+//    8 "type-2" steps: H = gelu(acc1 / s1 + b1) split to fp16 h|l IN REGISTERS is the B operand of fc2's MFMAs;
+//                      W2 tile 256 outputs x 16 (logical) k per step -> acc2[8] (persists over all chunks)
+// The accumulator layout of v_mfma_32x32x16 puts hidden rows (e&3) + 8 (e>>2) + 4 h of token `lane & 31` on
+// lane half h; a B fragment wants k = 8 h + j there.  fc2's k order is therefore permuted on the host inside
+// every aligned group of 16 hidden units (mlp_fused_perm16): registers 8q .. 8q+7 of a fc1 tile ARE the B
+// fragment of k-step q, with no LDS or HBM round trip (saves 8 KB per token and layer, one epilogue, one
+// prologue).  One ring of three 24 KiB LDS slots carries both kinds of step; loads run two steps ahead.
+// =====================================================================================
+constexpr int M_BT = 256, M_NW = 8, M_S = 3, M_HC = 128, M_D = 256;
+constexpr int M_A1 = 2 * 32 * M_HC * 2;        // fc1 weight tile: 2 planes x 32 k x 128 hidden, 16 KiB
+constexpr int M_SLOT = M_A1 + 32 * M_BT * 4;   // + X tile 32 k x 256 tokens fp32 = 48 KiB (fc2 tile: 32 KiB of it)
+constexpr int M_T1 = M_D / 32, M_T2 = M_HC / 32;  // steps per hidden chunk: 8 fc1 k-tiles, 4 fc2 k-tiles (32 deep)
+static_assert(H_BN == 128 && H_BT == 256 && H_NW == 8, "fused MLP reuses the gemm6 tile image");
+
+__host__ __device__ constexpr int mlp_perm16(int kappa) {  // logical k (8 h + j) -> hidden unit within the 16-group
+  return 4 * (kappa >> 3) + (kappa & 3) + 8 * ((kappa & 7) >> 2);
+}
+int mlp_fused_perm16(int kappa) { return mlp_perm16(kappa); }
+
+template <bool TANH>
+__global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
+  typedef SplitMode<1> SM;
+  typedef f16x8 svec;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[M_S * M_SLOT + 4096];
+  float* s_b1 = reinterpret_cast<float*>(smem + M_S * M_SLOT);  // fc1 bias, [N] (N <= 1024)
+
+  const unsigned nwg = gridDim.x;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t t_blk = (int64_t)bid * M_BT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_w = wave * 32;
+  const int i = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int n_hc = g.N / M_HC;
+  const int K8 = g.K >> 3, N8 = g.N >> 3;
+
+  for (int j = tid; j < g.N; j += 64 * M_NW) s_b1[j] = g.bias[j];
+  float rs, nm;
+  {
+    const int64_t t = t_blk + t_w + i;
+    float m = g.mean[t], r = g.rstd[t];  // sum / sum of squares over the K channels (fused statistics)
+    m = m / (float)g.K;
+    const float var = fmaxf(r / (float)g.K - m * m, 0.f);
+    r = 1.0f / sqrtf(var + g.ln_eps);
+    rs = r;
+    nm = -m * r;
+  }
+
+  // ---- LDS-DMA, 1 KiB per instruction, source = wave-uniform SGPR base + lane * 16 bytes.
+  //      type 1 (fc1 k-tile): 16 A1 pieces [plane][4 octets][2 x 64 hidden] + 32 X rows  -> 6 per wave
+  //      type 2 (fc2 k-tile): 32 A2 pieces [plane][4 octets][4 x 64 outputs]              -> 4 per wave
+  //      piece `idx` of a wave is piece number wave + 8 * idx of the tile ----
+  const uint32_t voff = lane * 16;
+  auto issue_one = [&](int hc, int s, int slot, int idx) {
+    const uint32_t base = lds0 + slot * M_SLOT;
+    const int q = wave + 8 * idx;
+    if (s < M_T1) {
+      if (idx < 2) {
+        const int pl = q >> 3, o = (q >> 1) & 3, seg = q & 1;
+        const unsigned short* a1 = g.Wp + ((((int64_t)pl * K8 + 4 * s + o) * g.N + hc * M_HC + seg * 64) << 3);
+        glds16_s(a1, voff, base + ((pl * 4 + o) * M_HC + seg * 64) * 16);
+      } else {
+        const int row = q - 16;
+        glds16_s(g.X + (int64_t)(32 * s + row) * g.Tp + t_blk, voff, base + M_A1 + row * 1024);
+      }
+    } else {
+      const int pl = q >> 4, o = (q >> 2) & 3, seg = q & 3;
+      const int64_t oct = 4 * ((int64_t)hc * M_T2 + (s - M_T1)) + o;
+      const unsigned short* a2 = g.Wp2 + ((((int64_t)pl * N8 + oct) * M_D + seg * 64) << 3);
+      glds16_s(a2, voff, base + ((pl * 4 + o) * M_D + seg * 64) * 16);
+    }
+  };
+  auto n_pieces = [](int s) { return s < M_T1 ? 6 : 4; };
+  auto issue_all = [&](int hc, int s, int slot) {
+    for (int idx = 0; idx < n_pieces(s); ++idx) issue_one(hc, s, slot, idx);
+  };
+
+  f32x16 acc1[4], acc2[8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc1[a][e] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
+  float mx = 0.f;
+
+  issue_all(0, 0, 0);
+  issue_all(0, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;  // slot of the step being consumed
+  // end of a step: the next step's tile has landed once only this step's `n_new` loads are outstanding
+  auto step_end = [&](int n_new) {
+    if (n_new == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n_new == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = cur + 1 == M_S ? 0 : cur + 1;
+  };
+
+  for (int hc = 0; hc < n_hc; ++hc) {
+    // ---------------- type 1: fc1, k-tiles of 32 ----------------
+    for (int kt = 0; kt < M_T1; ++kt) {
+      // the tile two steps ahead: steps kt + 2 of this chunk (fc2 tiles follow the fc1 tiles)
+      const int ns = kt + 2, nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+      const int n_new = n_pieces(ns);
+      static_for<2>([&](auto sc) {
+        constexpr int ss = decltype(sc)::value;
+        const uint32_t aA = lds0 + cur * M_SLOT + ((2 * ss + h) * M_HC + i) * 16;
+        const uint32_t aB = lds0 + cur * M_SLOT + M_A1 + ((16 * ss + 8 * h) * M_BT + t_w + i) * 4;
+        // reads in two waves of requests (X fragment + weight tiles 0, 1; then tiles 2, 3 behind the first MFMAs):
+        // at 256 VGPRs with 192 of them accumulators there is no room to hold all four weight tiles at once
+        f32x2 xb[4];
+        u32x4 afr[2][2];
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          xb[j] = lds_read2st64<4 * (2 * j), 4 * (2 * j + 1)>(aB);
+        });
+        afr[0][0] = lds_read_b128<(0 * M_HC + 0 * 32) * 16>(aA);
+        afr[0][1] = lds_read_b128<(4 * M_HC + 0 * 32) * 16>(aA);
+        afr[1][0] = lds_read_b128<(0 * M_HC + 1 * 32) * 16>(aA);
+        afr[1][1] = lds_read_b128<(4 * M_HC + 1 * 32) * 16>(aA);
+        lds_wait<4>(xb[0], xb[1], xb[2], xb[3]);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[2 * j] = fmaf(xb[j][0], rs, nm);
+          x[2 * j + 1] = fmaf(xb[j][1], rs, nm);
+        }
+        svec bs[2];
+        SM::split_mx(x, bs, mx);
+        auto group = [&](auto mc, u32x4 (&f)[2]) {
+          constexpr int mi = decltype(mc)::value;
+          const svec af[2] = {__builtin_bit_cast(svec, f[0]), __builtin_bit_cast(svec, f[1])};
+          acc1[mi] = SM::mma(af, bs, acc1[mi]);
+          constexpr int piece = 4 * ss + mi;  // spread the DMA issue between the MFMA groups
+          if constexpr (piece < 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (piece < n_new) issue_one(hc, ns, nslot, piece);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        lds_wait<2>(afr[0][0], afr[0][1]);
+        group(std::integral_constant<int, 0>{}, afr[0]);
+        lds_wait<0>(afr[1][0], afr[1][1]);
+        u32x4 afr2[2][2];
+        afr2[0][0] = lds_read_b128<(0 * M_HC + 2 * 32) * 16>(aA);
+        afr2[0][1] = lds_read_b128<(4 * M_HC + 2 * 32) * 16>(aA);
+        afr2[1][0] = lds_read_b128<(0 * M_HC + 3 * 32) * 16>(aA);
+        afr2[1][1] = lds_read_b128<(4 * M_HC + 3 * 32) * 16>(aA);
+        group(std::integral_constant<int, 1>{}, afr[1]);
+        lds_wait<2>(afr2[0][0], afr2[0][1]);
+        group(std::integral_constant<int, 2>{}, afr2[0]);
+        lds_wait<0>(afr2[1][0], afr2[1][1]);
+        group(std::integral_constant<int, 3>{}, afr2[1]);
+      });
+      step_end(n_new);
+    }
+    // ---------------- type 2: fc2 over this chunk's 128 hidden units, k-tiles of 32 (= one fc1 tile row) ----------------
+    static_for<M_T2>([&](auto kc) {
+      constexpr int mi = decltype(kc)::value;
+      // two steps ahead: fc2 tile mi + 2 of this chunk, or fc1 tile mi - 2 of the next chunk
+      const bool same = mi + 2 < M_T2;
+      const int ns = same ? M_T1 + mi + 2 : mi + 2 - M_T2, nhc = same ? hc : hc + 1;
+      const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+      const int n_new = nhc < n_hc ? n_pieces(ns) : 0;
+      static_for<2>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // B fragment: H = gelu(acc1 / s1 + b1) of hidden rows 32 mi + 16 q + 4 h + {0..3, 8..11}
+        const float* bp = s_b1 + hc * M_HC + mi * 32 + 16 * q + 4 * h;
+        const float4 b_lo = *reinterpret_cast<const float4*>(bp), b_hi = *reinterpret_cast<const float4*>(bp + 8);
+        const float bb[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = fmaf(acc1[mi][8 * q + j], g.w_inv_scale, bb[j]);
+          hv[j] = TANH ? gelu_tanh(v) : gelu_erf(v);
+        }
+        svec hf[2];
+        SM::split_mx(hv, hf, mx);
+        // A fragments of the 8 output tiles: one tile (2 reads) per batch, one batch ahead of its MFMAs
+        const uint32_t aW = lds0 + cur * M_SLOT + ((2 * q + h) * M_D + i) * 16;
+        u32x4 wf[2][2];  // [batch parity][plane]
+        auto load_w = [&](auto bc, u32x4 (&f)[2]) {
+          constexpr int b = decltype(bc)::value;
+          f[0] = lds_read_b128<(0 * M_D + b * 32) * 16>(aW);
+          f[1] = lds_read_b128<(4 * M_D + b * 32) * 16>(aW);
+        };
+        load_w(std::integral_constant<int, 0>{}, wf[0]);
+        static_for<8>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (b + 1 < 8) {
+            load_w(std::integral_constant<int, b + 1>{}, wf[(b + 1) & 1]);
+            lds_wait<2>(wf[b & 1][0], wf[b & 1][1]);
+          } else {
+            lds_wait<0>(wf[b & 1][0], wf[b & 1][1]);
+          }
+          const svec af[2] = {__builtin_bit_cast(svec, wf[b & 1][0]), __builtin_bit_cast(svec, wf[b & 1][1])};
+          acc2[b] = SM::mma(af, hf, acc2[b]);
+          constexpr int piece = 4 * q + (b >> 1);  // one DMA piece after every second tile
+          if constexpr ((b & 1) == 1 && piece < 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (piece < n_new) issue_one(nhc, ns, nslot, piece);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      });
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[mi][e] = 0.f;  // tile consumed: ready for the next chunk
+      step_end(n_new);
+    });
+  }
+  if (__any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
+
+  // ---- epilogue: x <- x + acc2 / s2 + b2, LayerNorm statistics of the result (all 256 channels are here) ----
+  GemmArgs e = g;
+  e.bias = g.bias2;
+  e.w_inv_scale = g.w_inv_scale2;
+  e.N = M_D;
+  e.stats_store = 1;
+  float* patch = reinterpret_cast<float*>(smem) + wave * 1024;
+  const int ii = lane & 31, hh = lane >> 5;
+  gemm_epilogue_lds_core<EPI_BIAS_RES_STATS, 8, 1>(
+      e,
+      [&](int mi, int, float* p) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ii] = acc2[mi][r];
+      },
+      patch, 0, t_blk + t_w, lane);
+}
+
+int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
+  DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
+  DC_REQUIRE(g.K == M_D && g.N % M_HC == 0 && g.N <= 1024 && g.Tp % M_BT == 0, "fused MLP: d_model 256, d_inner <= 1024");
+  DC_REQUIRE(g.X == g.R && g.mean && g.rstd && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
+  if (g.gelu_tanh)
+    hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3((unsigned)(g.Tp / M_BT)), dim3(64 * M_NW), 0, st, g);
+  else
+    hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3((unsigned)(g.Tp / M_BT)), dim3(64 * M_NW), 0, st, g);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
 }
 
 // Persistent variant of gemm6 for the short-K (K = 256) GEMMs: a workgroup walks several output tiles
