@@ -40,9 +40,12 @@ constexpr int G_RPW = G_BK / 4;  // tile rows staged by each of the 4 waves
 __device__ __forceinline__ float gelu_tanh(float x) {
   // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
   // == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one v_exp_f32 + one division
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  return __fdividef(x, 1.0f + __expf(-2.0f * u));
+  // seven VALU operations: v_exp_f32 and v_rcp_f32 are accurate to 1 ulp, far inside the 2e-4 parity budget;
+  // exp2 -> +inf gives x * 0 for very negative x, exp2 -> 0 gives x for very positive x
+  const float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+  const float c3 = c1 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(c3, x * x, c1));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
