@@ -37,11 +37,24 @@ FLOPS_PER_TOKEN = {
 FLOPS_PER_TOKEN_TOTAL = 8_916_992
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
-DOMINANT = "gemm_head2"       # head linear2 (1024x1024): 23.5 % of the algorithmic flops, one launch / step
-# HBM (L2-miss) bytes per token of the dominant kernel from the PMC passes committed in
-# profiles/r01_pmc_hbm_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / tokens, gfx950 correction applied.
-PMC_TRAFFIC_BYTES_PER_TOKEN = {"bf16x6": 14848064128.0 / 1025024, "fp16x3": 12255.0}  # profiles/r01_pmc_hbm_traffic*.json
-
+# Kernels that can be the step's dominant one (largest share of the forward time), with the HBM-side traffic per
+# padded token measured by the PMC passes committed under profiles/ ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950
+# correction applied) and the algorithmic bytes per token next to it.
+ROOFLINE_KERNELS = {
+    "mlp_fused": {
+        "fp16x3": {"kernel": "mlp_fused_kernel<true> (fc1 -> GELU -> fc2 -> +residual -> LN statistics, fp16x3)",
+                   "traffic_bpt": 10692.42, "source": "profiles/r01_pmc_hbm_traffic_mlpfused.json"},
+        "algorithmic_bpt": 2 * 1024 + 16,  # residual stream in and out (fp32) + statistics
+    },
+    "gemm_head2": {
+        "fp16x3": {"kernel": "gemm6_kernel<EPI_HEAD2_FUSED,false,1> (head linear2+3, K=N=1024, fp16x3)",
+                   "traffic_bpt": 11947.82, "source": "profiles/r01_pmc_hbm_traffic_mlpfused.json"},
+        "bf16x6": {"kernel": "gemm6_kernel<EPI_HEAD2_FUSED,false,0> (head linear2+3, K=N=1024, bf16x6)",
+                   "traffic_bpt": 14848064128.0 / 1025024, "source": "profiles/r01_pmc_hbm_traffic.json"},
+        "f32": {"kernel": "gemm_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024, fp32 MFMA)"},
+        "algorithmic_bpt": 2 * 1024 * 4 + 16,  # B operand + residual, fp32
+    },
+}
 
 def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
     """Time the CPU oracle (torch fp32 + numpy restatement of the same path, reference batch size
@@ -176,27 +189,26 @@ def main():
                 ent["tflops"] = round(FLOPS_PER_TOKEN[name] * tokens_per_launch / (avg_ms * 1e-3) / 1e12, 2)
             stages[name] = ent
         roof = None
-        if DOMINANT in stages:
-            ach = FLOPS_PER_TOKEN[DOMINANT] * tokens_per_launch / (stages[DOMINANT]["avg_ms"] * 1e-3) / 1e12
-            if args.gemm_mode == "bf16x6":
-                # fp32-equivalent GEMM executed as 6 bf16 MFMAs per algorithmic multiply-add: the roofline
-                # is the bf16 MFMA peak; `executed_frac` counts the 6x MFMA work actually issued.
-                peak, kern = PEAK_BF16_MFMA_TFLOPS, "gemm6_kernel<EPI_HEAD2_FUSED,false,0> (head linear2+3, K=N=1024, bf16x6)"
-            elif args.gemm_mode == "fp16x3":
-                # 2-way fp16 split, 3 fp16 MFMAs per algorithmic multiply-add (fp16 MFMA peak = bf16 peak)
-                peak, kern = PEAK_BF16_MFMA_TFLOPS, "gemm6_kernel<EPI_HEAD2_FUSED,false,1> (head linear2+3, K=N=1024, fp16x3)"
-            else:
-                peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024, fp32 MFMA)"
-            roof = {"bound": "mfma", "kernel": kern, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
-                    "avg_launch_ms": stages[DOMINANT]["avg_ms"],
-                    "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[DOMINANT] * tokens_per_launch}
-            if args.gemm_mode in PMC_TRAFFIC_BYTES_PER_TOKEN:
-                padded = -(-tokens_per_launch // 256) * 256
-                roof["traffic"] = int(PMC_TRAFFIC_BYTES_PER_TOKEN[args.gemm_mode] * padded)
-                roof["traffic_source"] = ("profiles/r01_pmc_hbm_traffic%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                                          % ("_fp16x3" if args.gemm_mode == "fp16x3" else ""))
-                roof["algorithmic_hbm_bytes_per_launch"] = int(padded * (2 * 1024 * 4 + 16))  # B operand + residual, fp32
+        cands = [k for k in ROOFLINE_KERNELS if k in stages]
+        if cands:
+            # the dominant kernel = the one with the largest share of the forward time (all its launches of a step)
+            dom = max(cands, key=lambda k: stages[k]["share"])
+            info = ROOFLINE_KERNELS[dom]
+            mode = info.get(args.gemm_mode, {})
+            ach = FLOPS_PER_TOKEN[dom] * tokens_per_launch / (stages[dom]["avg_ms"] * 1e-3) / 1e12
+            # f32: fp32 MFMA peak.  bf16x6 / fp16x3: the 16-bit MFMA dense peak; `executed_frac` counts the 6x / 3x
+            # MFMA work actually issued per algorithmic multiply-add
+            peak = PEAK_F32_MFMA_TFLOPS if args.gemm_mode == "f32" else PEAK_BF16_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": mode.get("kernel", dom), "stage": dom, "achieved": round(ach, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_ms": stages[dom]["avg_ms"], "launches_per_step": stages[dom]["launches"] // max(args.steps, 1),
+                    "share_of_forward": stages[dom]["share"],
+                    "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[dom] * tokens_per_launch}
+            if "traffic_bpt" in mode:
+                padded = -(-(B * (-(-(L + 1) // 32) * 32)) // 256) * 256  # reads start at multiples of 32 token slots
+                roof["traffic"] = int(mode["traffic_bpt"] * padded)
+                roof["traffic_source"] = mode["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                roof["algorithmic_hbm_bytes_per_launch"] = int(padded * info["algorithmic_bpt"])
             if args.gemm_mode in ("bf16x6", "fp16x3"):
                 mult = 6 if args.gemm_mode == "bf16x6" else 3
                 roof["mfma_per_algorithmic_fma"] = mult

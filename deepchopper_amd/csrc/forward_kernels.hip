@@ -1924,7 +1924,10 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
 }
 
 template <int CB, int MODE>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16
-__global__ __launch_bounds__(256, 2) void hyena3_kernel(HyenaArgs a) {
+#ifndef DC_H3_OCC
+#define DC_H3_OCC 2
+#endif
+__global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   typedef SplitMode<MODE> SM;
   typedef typename SM::vec svec;
   constexpr int NP = SM::NP;
@@ -2108,7 +2111,8 @@ static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if (max_P <= 32) {
+  static const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
+  if (max_P <= 32 && !cb16) {
     hipLaunchKernelGGL((hyena3_kernel<32, MODE>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
   } else {
     hipLaunchKernelGGL((hyena3_kernel<16, MODE>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
