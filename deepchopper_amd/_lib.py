@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dc_model_device_bytes": (i64, [vp]),
     "dc_model_filter": (C.c_int, [vp, vp, i32, i32, vp]),
     "dc_model_set_gemm_mode": (C.c_int, [vp, i32]),
+    "dc_model_set_mlp_fusion": (C.c_int, [vp, i32]),
     "dc_model_overflow": (C.c_int, [vp, vp, C.POINTER(i32)]),
     "dc_model_set_profiling": (C.c_int, [vp, i32]),
     "dc_model_profile_reset": (C.c_int, [vp]),

@@ -55,6 +55,7 @@ struct dc_model {
   float is_l1 = 1.f, is_l2 = 1.f;
   int* d_overflow = nullptr;  // fp16x3 range guard (device counter)
   float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
+  int mlp_fusion = 1;  // fp16x3: fc1 -> GELU -> fc2 in one kernel (dc_model_set_mlp_fusion)
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   std::vector<void*> owned;  // every weight allocation
@@ -571,7 +572,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
     static const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
-    if (m->gemm_mode == 2 && sums && !no_mlp_fuse && L.Wq_fc2p && D == 256 && DI % 128 == 0 && DI <= 1024) {
+    if (m->gemm_mode == 2 && sums && !no_mlp_fuse && m->mlp_fusion && L.Wq_fc2p && D == 256 && DI % 128 == 0 && DI <= 1024) {
       // fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide activation stays
       // in registers (fp16x3 only)
       GemmArgs g{};
@@ -830,6 +831,12 @@ extern "C" int dc_model_set_gemm_mode(dc_model* m, int32_t mode) {
   DC_REQUIRE(m, "null pointer");
   DC_REQUIRE(mode >= 0 && mode <= 2, "gemm mode must be 0 (fp32 MFMA), 1 (bf16x6) or 2 (fp16x3)");
   m->gemm_mode = mode;
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_mlp_fusion(dc_model* m, int32_t on) {
+  DC_REQUIRE(m, "null pointer");
+  m->mlp_fusion = on ? 1 : 0;
   return DC_OK;
 }
 

@@ -185,6 +185,42 @@ def test_gemm_modes_error_vs_float64(hip_lib):
     assert errs["bf16x6"] < 4 * max(errs["f32"], errs["oracle_f32"]) + 1e-6
 
 
+@pytest.mark.parametrize("d_inner,gelu", [(1024, "tanh"), (512, "tanh"), (1024, "none"), (384, "tanh")])
+def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
+    """fp16x3: the fused MLP kernel (fc1 -> GELU -> fc2 with the hidden activation in registers, fc2's k order
+    permuted on the host) against the two-GEMM form of the same build and against the oracle, for the reference
+    shape, a narrower MLP (4 hidden chunks), the erf GELU, and a width the fused kernel does not take
+    (d_inner % 128 != 0 -> the switch is a no-op and both runs use the two-kernel form)."""
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    cfg = HyenaDNAConfig(d_inner=d_inner, gelu_approximate=gelu)
+    sd = synthetic_state_dict(11, cfg)
+    model = ops.HipModel(sd, cfg)
+    assert model.gemm_mode == "fp16x3"
+    rng = np.random.default_rng(d_inner)
+    ids, q = _inputs(rng, 5, 333)
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    model.set_profiling(True)
+    fused = model.forward(d_ids, d_q).cpu().numpy()
+    stages = model.profile()
+    model.profile_reset()
+    model.set_mlp_fusion(False)
+    plain = model.forward(d_ids, d_q).cpu().numpy()
+    stages_plain = model.profile()
+    takes = d_inner % 128 == 0
+    ran = lambda st, name: st.get(name, (0.0, 0))[1] > 0
+    assert ran(stages, "mlp_fused") == takes and ran(stages, "gemm_fc1") == (not takes)
+    assert not ran(stages_plain, "mlp_fused") and ran(stages_plain, "gemm_fc1") and ran(stages_plain, "gemm_fc2")
+    ref = fr.forward(sd, ids, q, fr.HyenaDNAConfig(d_inner=d_inner, gelu_approximate=gelu)).numpy()
+    _check(fused, ref)
+    _check(plain, ref)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(fused - plain).max() < 5e-5 * scale  # same split arithmetic, different summation order only
+    assert model.overflow() == 0
+
+
 @pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001)])
 def test_forward_long_reads_match_oracle(env, B, L):
     """BASELINE configs 3 and 4: 2 kb reads and reads up to 10 kb (several 32-block output chunks of the
