@@ -231,6 +231,10 @@ int ensure(DevBuf& b, size_t bytes) {
   b.p = nullptr;
   b.bytes = 0;
   DC_HIP_CHECK(hipMalloc(&b.p, bytes));
+  // Token slots that belong to no read (the tail up to the 256-token tile) are computed but never meaningful;
+  // the long-convolution kernel does not write them.  Starting from zeros keeps them finite for good, so they
+  // can neither trip the fp16 range guard nor feed NaNs into the LayerNorm statistics of their tile.
+  DC_HIP_CHECK(hipMemset(b.p, 0, bytes));
   b.bytes = bytes;
   return DC_OK;
 }

@@ -2016,9 +2016,32 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
     const int u_base = NT / 8 - 4 - 4 * d_hi;
     const int n_units = 4 * (d_hi - d_lo) + 8;  // <= 132 <= H3_CS
     __syncthreads();                            // previous window / z tiles no longer in use
-    for (int idx = tid; idx < NP * 8 * n_units; idx += 256) {
-      const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
-      reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+    if constexpr (NP == 3) {  // bf16x6: no registers to spare next to the 128 accumulators
+      for (int idx = tid; idx < NP * 8 * n_units; idx += 256) {
+        const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
+        reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+      }
+    } else {  // filter window -> LDS: all of a thread's loads in flight before the first LDS write (the rolled
+              // loop paid one L2 round trip per 16 bytes)
+      constexpr int NW_IT = (NP * 8 * 132 + 255) / 256;  // n_units <= 132
+      svec wtmp[NW_IT];
+      const int n_w = NP * 8 * n_units;
+#pragma unroll
+      for (int k = 0; k < NW_IT; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < n_w) {
+          const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
+          wtmp[k] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NW_IT; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < n_w) {
+          const int cp = idx / n_units, j = idx - cp * n_units;
+          reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = wtmp[k];
+        }
+      }
     }
     {
       float4 l1, c1, lv, cv;
