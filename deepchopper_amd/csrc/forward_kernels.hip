@@ -1934,6 +1934,7 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   constexpr int H3_FILT_BYTES = h3_filt_bytes(NP), H3_ZBUF_BYTES = h3_zbuf_bytes(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_h3[];
   constexpr int NACC = CB / 4;
+  DC_STAMP_T(st0);
   const int g = blockIdx.x, c = blockIdx.y, oc = blockIdx.z;
   const int P = a.grp_P[g];
   if (CB * oc >= P) return;  // block-uniform
@@ -2006,6 +2007,9 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   const int u_c = (Mx - sg - r32) >> 3;
   const svec* gfp = reinterpret_cast<const svec*>(MODE == 1 ? a.kfp_f16 : a.kfp) + (int64_t)c * NP * 8 * a.kfp_nu;
 
+#ifdef DC_STAMP
+  unsigned long long st_loop0 = 0;
+#endif
   const int n_ic = oc + 1;  // input chunks 0 .. oc
   for (int ic = 0; ic < n_ic; ++ic) {
     const int p_in0 = CB * ic;
@@ -2049,6 +2053,9 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
       z_store(p_in0, l1, c1, lv, cv);
     }
     __syncthreads();
+#ifdef DC_STAMP
+    if (ic == 0) st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int p = p_in0; p <= p_in_last; ++p) {
       float4 l1, c1, lv, cv;
@@ -2085,6 +2092,7 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
     }
   }
 
+  DC_STAMP_T(st2);
   // ---- epilogue: C[read][q'] -> patch -> row-wise: y = conv * sf(x0), 16 B per lane ----
   // (all waves passed the last barrier: the filter window is dead, each wave takes a 32 x 33 patch of it)
   float* patch = reinterpret_cast<float*>(s_filt) + wave * (32 * 33);
@@ -2099,16 +2107,28 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
   const float inv_sc = MODE == 1 ? a.ch_inv_scale[c] : 1.0f;  // fp16x3: undo the filter's power-of-two scale
   if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
+  // x0 windows are requested one output block ahead of their use: fetched when needed, each of the (up to) eight
+  // blocks of a wave paid a full memory round trip (a quarter of the kernel was this epilogue)
+  float wq[2][20];
+  {
+    const int pp0 = p_out0 + wave;
+    const int64_t t00 = 32 * pp0 + eh;
+    load_window20(ux0, t00, t00 > 0, pp0 <= p_out_last && pp0 < e_nblk, wq[0]);
+  }
 #pragma unroll
   for (int m = 0; m < NACC; ++m) {
     const int pp = p_out0 + wave + 4 * m;
+    if (m + 1 < NACC) {
+      const int ppn = pp + 4;
+      const int64_t tn = 32 * ppn + eh;
+      load_window20(ux0, tn, true, ppn <= p_out_last && ppn < e_nblk, wq[(m + 1) & 1]);
+    }
     if (pp <= p_out_last) {  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r32] = acc[m][e];
       if (pp < e_nblk) {
         const int64_t t0 = 32 * pp + eh;
-        float w[20];
-        load_window20(ux0, t0, t0 > 0, true, w);
+        const float(&w)[20] = wq[m & 1];
         float o[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -2121,6 +2141,16 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
       }
     }
   }
+#ifdef DC_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DC_STAMP_T(st3);
+  if (lane == 0) {
+    atomicAdd(&dc_stamps[7][0], st_loop0 - st0);
+    atomicAdd(&dc_stamps[7][1], st2 - st_loop0);
+    atomicAdd(&dc_stamps[7][2], st3 - st2);
+    atomicAdd(&dc_stamps[7][3], 1ull);
+  }
+#endif
 }
 
 template <int MODE>

@@ -30,12 +30,13 @@ for _ in range(3):
     model.net.forward(d_ids, d_q)
 torch.cuda.synchronize()
 L.dc_debug_read_stamps(buf)
-names = {0: "in_proj", 2: "fc1(gelu)", 3: "head1", 5: "head2", 6: "out_proj+fc2"}
+names = {0: "in_proj", 2: "fc1(gelu)", 3: "head1", 5: "head2", 6: "out_proj(+fc2)", 7: "hyena3"}
 for e, n in names.items():
     pro, loop, epi, waves = buf[4 * e], buf[4 * e + 1], buf[4 * e + 2], buf[4 * e + 3]
     if waves:
         tot = pro + loop + epi
         rt = buf[32 + e]
-        print(f"   clock {tot / rt * 100:.0f} MHz (memtime / memrealtime), wave lifetime {rt / waves / 100:.1f} us")
+        if rt:
+            print(f"   clock {tot / rt * 100:.0f} MHz (memtime / memrealtime), wave lifetime {rt / waves / 100:.1f} us")
         print(f"{n:14s} waves {waves:9d}  prologue {pro / waves:8.0f} ({100 * pro / tot:4.1f}%)  loop {loop / waves:8.0f} "
               f"({100 * loop / tot:4.1f}%)  epilogue {epi / waves:8.0f} ({100 * epi / tot:4.1f}%)  cycles/wave")
