@@ -927,6 +927,9 @@ __host__ __device__ constexpr int mlp_perm16(int kappa) {  // logical k (8 h + j
 }
 int mlp_fused_perm16(int kappa) { return mlp_perm16(kappa); }
 
+#ifndef DC_M_ILV
+#define DC_M_ILV 1  // fused MLP: LDS-DMA pieces of the tile two steps ahead issued between the MFMA groups
+#endif
 template <bool TANH>
 __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   typedef SplitMode<1> SM;
@@ -1022,6 +1025,9 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
       // the tile two steps ahead: steps kt + 2 of this chunk (fc2 tiles follow the fc1 tiles)
       const int ns = kt + 2, nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
       const int n_new = n_pieces(ns);
+#if !DC_M_ILV
+      for (int idx = 0; idx < n_new; ++idx) issue_one(hc, ns, nslot, idx);
+#endif
       static_for<2>([&](auto sc) {
         constexpr int ss = decltype(sc)::value;
         const uint32_t aA = lds0 + cur * M_SLOT + ((2 * ss + h) * M_HC + i) * 16;
@@ -1052,11 +1058,13 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
           const svec af[2] = {__builtin_bit_cast(svec, f[0]), __builtin_bit_cast(svec, f[1])};
           acc1[mi] = SM::mma(af, bs, acc1[mi]);
           constexpr int piece = 4 * ss + mi;  // spread the DMA issue between the MFMA groups
+#if DC_M_ILV
           if constexpr (piece < 6) {
             __builtin_amdgcn_sched_barrier(0);
             if (piece < n_new) issue_one(hc, ns, nslot, piece);
             __builtin_amdgcn_sched_barrier(0);
           }
+#endif
         };
         lds_wait<2>(afr[0][0], afr[0][1]);
         group(std::integral_constant<int, 0>{}, afr[0]);
@@ -1082,6 +1090,9 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
       const int ns = same ? M_T1 + mi + 2 : mi + 2 - M_T2, nhc = same ? hc : hc + 1;
       const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
       const int n_new = nhc < n_hc ? n_pieces(ns) : 0;
+#if !DC_M_ILV
+      for (int idx = 0; idx < n_new; ++idx) issue_one(nhc, ns, nslot, idx);
+#endif
       static_for<2>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         // B fragment: H = gelu(acc1 / s1 + b1) of hidden rows 32 mi + 16 q + 4 h + {0..3, 8..11}
@@ -1116,11 +1127,13 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
           const svec af[2] = {__builtin_bit_cast(svec, wf[b & 1][0]), __builtin_bit_cast(svec, wf[b & 1][1])};
           acc2[b] = SM::mma(af, hf, acc2[b]);
           constexpr int piece = 4 * q + (b >> 1);  // one DMA piece after every second tile
+#if DC_M_ILV
           if constexpr ((b & 1) == 1 && piece < 6) {
             __builtin_amdgcn_sched_barrier(0);
             if (piece < n_new) issue_one(nhc, ns, nslot, piece);
             __builtin_amdgcn_sched_barrier(0);
           }
+#endif
         });
       });
 #pragma unroll
