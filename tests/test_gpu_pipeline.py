@@ -243,3 +243,27 @@ def test_cli_two_ranks_shard_the_file(env, tmp_path):
     assert [l.split("\t")[0] for l in single.strip().split("\n")] == ids
     assert two == single
     assert sorted(os.listdir(tmp_path / "w2" / "0")) == ["0.intervals.tsv", "1.intervals.tsv"]
+
+
+def test_single_read_api_matches_oracle(env):
+    """ui/main.py:53-106 `predict(text)`: intervals JSON + highlighted segments for one FASTQ record."""
+    torch, sd, pipe = env
+    from deepchopper_amd import synth, ui
+    from oracle import dc_oracle as o
+
+    seq, qual, ids = synth.synth_reads_fixed(1, 900, seed=7)
+    s, q = seq[0].tobytes().decode(), qual[0].tobytes().decode()
+    text = f"@{ids[0]}\n{s}\n+\n{q}\n"
+    # permissive policy: synthetic weights give many short intervals
+    js, hl = ui.predict(text, 21, 5, 200, 200, model=pipe.model)
+    ref, _ = pipe.predict_reads([ids[0]], [s.encode()], [q.encode()])
+    labels = ref[0]["prediction"]
+    exp = o.smooth_label_region(labels, 21, 5, 200)
+    assert [(d["start"], d["end"]) for d in js] == exp and len(exp) > 0
+    assert all(tag in ("ada", None) for _, tag in hl)
+    kept = o.generate_unmaped_intervals(exp, len(s))
+    assert [t for t, tag in hl if tag == "ada"] == [s[a:b] for a, b in exp]
+    assert [t for t, tag in hl if tag is None] == [s[a:b] for a, b in kept]
+    assert ui.predict(text, 21, 13, 20, 0, model=pipe.model) == ([], [])  # more intervals than max_process_intervals
+    with pytest.raises(ValueError):
+        list(ui.parse_fq_record("@r\nACGT\n+\n"))
