@@ -46,6 +46,14 @@ struct GemmArgs {
   const float* bias2;         // [K]
   float w_inv_scale2;
   int stats_store;            // EPI_BIAS_RES_STATS: 1 = this workgroup owns all channels of its tokens: plain stores
+  // fused MLP, optional third matrix: the GEMM that consumes LayerNorm(new residual stream) -- the next block's
+  // in_proj (epi3 = EPI_BIAS) or the head's linear1 (epi3 = EPI_BIAS_RELU_Q, with q) -- K -> N3 outputs, k order
+  // permuted like Wp2 (the new residual stream is its B operand straight from the accumulator registers)
+  const unsigned short* Wp3;  // [2][K/8][N3][8] or nullptr
+  const float* bias3;         // [N3] (LayerNorm-beta folded)
+  float w_inv_scale3;
+  int N3, epi3;
+  float* C3;                  // [N3][Tp]
 };
 
 struct FilterArgs {

@@ -26,6 +26,7 @@ struct LayerDev {
   unsigned short *Wp_in = nullptr, *Wp_out = nullptr, *Wp_fc1 = nullptr, *Wp_fc2 = nullptr;  // bf16 planes
   unsigned short *Wq_in = nullptr, *Wq_out = nullptr, *Wq_fc1 = nullptr, *Wq_fc2 = nullptr;  // fp16 planes (scaled)
   unsigned short* Wq_fc2p = nullptr;  // fc2 planes with the k order of the fused MLP kernel (mlp_fused_perm16)
+  unsigned short* Wq_inp = nullptr;   // in_proj planes in that k order (B operand = the previous block's MLP output)
   float is_in = 1.f, is_out = 1.f, is_fc1 = 1.f, is_fc2 = 1.f;                              // 1 / weight scale
   // implicit filter parameters (device copies, checkpoint layout)
   float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
@@ -52,6 +53,8 @@ struct dc_model {
   float *Wt_l1 = nullptr, *b_l1 = nullptr, *Wt_l2 = nullptr, *b_l2 = nullptr, *W3 = nullptr, *b3 = nullptr;
   unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
   unsigned short *Wq_l1 = nullptr, *Wq_l2 = nullptr;
+  unsigned short* Wq_l1p = nullptr;  // head linear1 planes in the fused MLP kernel's k order
+  int mlp_chain = 1;                 // fused MLP kernel also runs the GEMM that consumes LayerNorm(its output)
   float is_l1 = 1.f, is_l2 = 1.f;
   int* d_overflow = nullptr;  // fp16x3 range guard (device counter)
   float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
@@ -520,10 +523,13 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   const int nchunk_min = (m->max_P + 3) / 4;
   const int CH = nchunk_min >= 7 ? 1 : (nchunk_min >= 3 ? 2 : 4);
 
+  static const bool no_mlp_chain = getenv("DC_NO_MLP_CHAIN") != nullptr;  // A/B switch
+  bool u_ready = false;     // the previous block's fused MLP kernel already produced this block's in_proj output
+  bool head1_ready = false;  // ... or the head's linear1 output (last block)
   for (int li = 0; li < c.n_layer; ++li) {
     LayerDev& L = m->layers[li];
     const bool sums = fused_stats && l0_table;  // statistics of x come from the previous producer's epilogue
-    if (!(li == 0 && l0_table)) {  // layer 0: u was gathered from the per-token-id table by the embed kernel
+    if (!(li == 0 && l0_table) && !u_ready) {  // layer 0: u was gathered from the per-token-id table by the embed kernel
       if (!sums) {
         ProfScope ps(m, st, "ln_stats");
         if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
@@ -601,9 +607,33 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       g.N = DI;
       g.Tp = Tp;
       g.gelu_tanh = c.gelu_tanh;
-      ProfScope ps(m, st, "mlp_fused");
+      // chain: the GEMM that consumes LayerNorm(this block's output) runs inside the same kernel, its B operand
+      // taken from the accumulator registers: the next block's in_proj, or the head's linear1 after the last block
+      u_ready = false;
+      const bool chain = !no_mlp_chain && m->mlp_chain;
+      if (chain && li + 1 < c.n_layer && m->layers[li + 1].Wq_inp && (3 * D) % 128 == 0) {
+        LayerDev& Ln = m->layers[li + 1];
+        g.Wp3 = Ln.Wq_inp;
+        g.bias3 = Ln.b_in;
+        g.w_inv_scale3 = Ln.is_in;
+        g.N3 = 3 * D;
+        g.epi3 = EPI_BIAS;
+        g.C3 = u;
+        u_ready = true;
+      } else if (chain && li + 1 == c.n_layer && m->Wq_l1p && H % 128 == 0) {
+        g.Wp3 = m->Wq_l1p;
+        g.bias3 = m->b_l1;
+        g.w_inv_scale3 = m->is_l1;
+        g.N3 = H;
+        g.epi3 = EPI_BIAS_RELU_Q;
+        g.C3 = hm;
+        g.q = qpad;
+        head1_ready = true;
+      }
+      ProfScope ps(m, st, g.Wp3 ? (g.epi3 == EPI_BIAS ? "mlp_inproj_fused" : "mlp_head1_fused") : "mlp_fused");
       if ((rc = launch_mlp_fused(st, g))) return rc;
     } else {
+      u_ready = false;
       if ((rc = run_gemm(m, st, "gemm_fc1", WRef{L.Wt_fc1, L.Wp_fc1, L.Wq_fc1, L.is_fc1}, x, hm, L.b_fc1, nullptr, nullptr, true,
                          EPI_BIAS_GELU, D, DI, sums)))
         return rc;
@@ -614,11 +644,12 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
     }
   }
   const bool head_sums = fused_stats && l0_table;
-  if (!head_sums) {
+  if (!head_sums && !head1_ready) {
     ProfScope ps(m, st, "ln_stats");
     if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
   }
-  if ((rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
+  if (!head1_ready &&
+      (rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
                      head_sums)))
     return rc;
   static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
@@ -691,6 +722,13 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     UP(upload(m, Wt, &L.Wt_in));
     UP(upload_planes(m, Wt, D, 3 * D, &L.Wp_in));
     UP(upload_planes_f16(m, Wt, D, 3 * D, &L.Wq_in, &L.is_in));
+    if (D % 16 == 0) {  // k order of the fused MLP kernel's third GEMM
+      std::vector<float> Wtp((size_t)D * 3 * D);
+      for (int k = 0; k < D; ++k)
+        memcpy(&Wtp[(size_t)k * 3 * D], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * 3 * D], (size_t)3 * D * sizeof(float));
+      float is_p = 0.f;
+      UP(upload_planes_f16(m, Wtp, D, 3 * D, &L.Wq_inp, &is_p));
+    }
     if (li == 0) {
       // u0[v][n] = b'[n] + sum_k Wt[k][n] * (emb[v][k] - mean_v) * rstd_v   (gamma / beta already folded), fp64
       std::vector<float> tab((size_t)cfg->vocab * 3 * D);
@@ -754,6 +792,13 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   UP(upload(m, Wt, &m->Wt_l1));
   UP(upload_planes(m, Wt, D, H, &m->Wp_l1));
   UP(upload_planes_f16(m, Wt, D, H, &m->Wq_l1, &m->is_l1));
+  if (D % 16 == 0) {
+    std::vector<float> Wtp((size_t)D * H);
+    for (int k = 0; k < D; ++k)
+      memcpy(&Wtp[(size_t)k * H], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * H], (size_t)H * sizeof(float));
+    float is_p = 0.f;
+    UP(upload_planes_f16(m, Wtp, D, H, &m->Wq_l1p, &is_p));
+  }
   UP(upload(m, bo, &m->b_l1));
   fold_transpose(w->head_w2, w->head_b2, nullptr, nullptr, H, H, Wt, bo);
   UP(upload(m, Wt, &m->Wt_l2));
@@ -841,6 +886,7 @@ extern "C" int dc_model_set_gemm_mode(dc_model* m, int32_t mode) {
 extern "C" int dc_model_set_mlp_fusion(dc_model* m, int32_t on) {
   DC_REQUIRE(m, "null pointer");
   m->mlp_fusion = on ? 1 : 0;
+  m->mlp_chain = on >= 2 || on < 0 ? 1 : 0;  // 1: MLP only; 2 (default state): MLP + the GEMM after it
   return DC_OK;
 }
 

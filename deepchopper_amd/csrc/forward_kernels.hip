@@ -930,7 +930,7 @@ int mlp_fused_perm16(int kappa) { return mlp_perm16(kappa); }
 #ifndef DC_M_ILV
 #define DC_M_ILV 1  // fused MLP: LDS-DMA pieces of the tile two steps ahead issued between the MFMA groups
 #endif
-template <bool TANH>
+template <bool TANH, int EPI3>  // EPI3: -1, or the epilogue of the fused third GEMM (EPI_BIAS / EPI_BIAS_RELU_Q)
 __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   typedef SplitMode<1> SM;
   typedef f16x8 svec;
@@ -1143,31 +1143,187 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   }
   if (__any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
 
-  // ---- epilogue: x <- x + acc2 / s2 + b2, LayerNorm statistics of the result (all 256 channels are here) ----
-  GemmArgs e = g;
-  e.bias = g.bias2;
-  e.w_inv_scale = g.w_inv_scale2;
-  e.N = M_D;
-  e.stats_store = 1;
-  float* patch = reinterpret_cast<float*>(smem) + wave * 1024;
-  const int ii = lane & 31, hh = lane >> 5;
-  gemm_epilogue_lds_core<EPI_BIAS_RES_STATS, 8, 1>(
-      e,
-      [&](int mi, int, float* p) {
+  if constexpr (EPI3 < 0) {
+    // ---- epilogue: x <- x + acc2 / s2 + b2, LayerNorm statistics of the result (all 256 channels are here) ----
+    GemmArgs e = g;
+    e.bias = g.bias2;
+    e.w_inv_scale = g.w_inv_scale2;
+    e.N = M_D;
+    e.stats_store = 1;
+    float* patch = reinterpret_cast<float*>(smem) + wave * 1024;
+    const int ii = lane & 31, hh = lane >> 5;
+    gemm_epilogue_lds_core<EPI_BIAS_RES_STATS, 8, 1>(
+        e,
+        [&](int mi, int, float* p) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ii] = acc2[mi][r];
-      },
-      patch, 0, t_blk + t_w, lane);
+          for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ii] = acc2[mi][r];
+        },
+        patch, 0, t_blk + t_w, lane);
+  } else {
+    // =============== third GEMM: C3 = epi3(W3 . LayerNorm(x_new)), x_new = x + acc2 / s2 + b2 ===============
+    // The new residual stream is needed (a) in HBM, (b) as this GEMM's B operand.  It is formed in the
+    // accumulator layout (hidden... channel rows on registers, token on the lane), where -- with W3's k order permuted
+    // like fc2's -- registers 8q .. 8q+7 of a tile are again a B fragment.  LayerNorm statistics come from the
+    // registers (this wave holds all 256 channels of its 32 tokens, split over the two lane halves).
+    const int n_mb = g.N3 / M_HC;
+    // W3 tile of one step: 64 deep, [plane][8 octets][128 rows][8] = 32 KiB at the slot base; 32 pieces, 4 per wave
+    constexpr int M_T3 = M_D / 64;  // steps per 128-row block of C3
+    auto issue3 = [&](int mb, int s3, int slot, int idx) {
+      const int q = wave + 8 * idx, pl = q >> 4, o = (q >> 1) & 7, seg = q & 1;
+      const unsigned short* a3 = g.Wp3 + ((((int64_t)pl * K8 + 8 * s3 + o) * g.N3 + mb * M_HC + seg * 64) << 3);
+      glds16_s(a3, voff, lds0 + slot * M_SLOT + ((pl * 8 + o) * M_HC + seg * 64) * 16);
+    };
+    // the ring is drained here (the last fc2 steps issued nothing): restart it while x_new is being formed
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) issue3(0, 0, 0, idx);
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) issue3(0, 1, 1, idx);
+    const int64_t tcol = t_blk + t_w + i;
+    float s_sum = 0.f, s_sq = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row0 = 32 * tl + 8 * gq + 4 * h;
+        const float4 b4 = *reinterpret_cast<const float4*>(g.bias2 + row0);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xo = g.X[(int64_t)(row0 + r) * g.Tp + tcol];
+          const float xn = fmaf(acc2[tl][4 * gq + r], g.w_inv_scale2, bb[r]) + xo;
+          acc2[tl][4 * gq + r] = xn;
+          s_sum += xn;
+          s_sq = fmaf(xn, xn, s_sq);
+        }
+      }
+    }
+    s_sum += __shfl_xor(s_sum, 32, 64);
+    s_sq += __shfl_xor(s_sq, 32, 64);
+    if (h == 0) {  // statistics of the new stream for whoever normalises it later (final LayerNorm of a later kernel)
+      g.st_sum[tcol] = s_sum;
+      g.st_sq[tcol] = s_sq;
+    }
+    // x_new -> HBM through the per-wave LDS patch (row-wise 16-byte stores); the patches live in the 16 KiB that
+    // the 32 KiB W3 tiles leave free at the top of slots 0 and 1 (four waves each)
+    float* patch = reinterpret_cast<float*>(smem + (wave >> 2) * M_SLOT + 32768) + (wave & 3) * 1024;
+    {
+      const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int tl = 0; tl < 8; ++tl) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc2[tl][r];
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const float4 v = *reinterpret_cast<const float4*>(patch + (p4 * 8 + rr) * 32 + c4);
+          *reinterpret_cast<float4*>(g.C + (int64_t)(32 * tl + p4 * 8 + rr) * g.Tp + t_blk + t_w + c4) = v;
+        }
+      }
+    }
+    // LayerNorm + fp16 split in place: 16 B fragments (k-steps of 16 channels) of this wave's 32 tokens
+    float rs3, nm3;
+    {
+      const float m = s_sum / (float)M_D;
+      const float var = fmaxf(s_sq / (float)M_D - m * m, 0.f);
+      rs3 = 1.0f / sqrtf(var + g.ln_eps);
+      nm3 = -m * rs3;
+    }
+    svec xs[16][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float xv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xv[r] = fmaf(acc2[j >> 1][8 * (j & 1) + r], rs3, nm3);
+      SM::split_mx(xv, xs[j], mx);
+    }
+    f32x16 acc3[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[a][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = 0;
+    GemmArgs e3 = g;
+    e3.bias = g.bias3;
+    e3.w_inv_scale = g.w_inv_scale3;
+    e3.N = g.N3;
+    e3.C = g.C3;
+    bool after_epi = false;  // the stores of a block's epilogue sit between the ring's loads in the vmcnt order
+    for (int mb = 0; mb < n_mb; ++mb) {
+      static_for<M_T3>([&](auto sc3) {
+        constexpr int s3 = decltype(sc3)::value;
+        const bool same = s3 + 2 < M_T3;
+        const int ns3 = same ? s3 + 2 : s3 + 2 - M_T3, nmb = same ? mb : mb + 1;
+        const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+        const bool more = nmb < n_mb;
+        static_for<4>([&](auto ssc) {
+          constexpr int ss = decltype(ssc)::value;
+          const uint32_t aA = lds0 + cur * M_SLOT + ((2 * ss + h) * M_HC + i) * 16;
+          u32x4 afr[4][2];
+          static_for<4>([&](auto mc) {
+            constexpr int mi = decltype(mc)::value;
+            afr[mi][0] = lds_read_b128<(0 * M_HC + mi * 32) * 16>(aA);
+            afr[mi][1] = lds_read_b128<(8 * M_HC + mi * 32) * 16>(aA);
+          });
+          static_for<4>([&](auto mc) {
+            constexpr int mi = decltype(mc)::value;
+            lds_wait<2 * (3 - mi)>(afr[mi][0], afr[mi][1]);
+            const svec af[2] = {__builtin_bit_cast(svec, afr[mi][0]), __builtin_bit_cast(svec, afr[mi][1])};
+            acc3[mi] = SM::mma(af, xs[4 * s3 + ss], acc3[mi]);
+            if constexpr (mi == 1) {  // the four DMA pieces of the tile two steps ahead, one per sub-step
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue3(nmb, ns3, nslot, ss);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        });
+        // next step's tile has landed once only this step's 4 pieces (and, right after a block epilogue, its
+        // 16 younger-than-that-tile stores) are outstanding
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epi) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        after_epi = false;
+        __syncthreads();
+        cur = cur + 1 == M_S ? 0 : cur + 1;
+      });
+      after_epi = true;
+      // epilogue of this 128-row block of C3; the ring keeps its two tiles in flight below the patch
+      gemm_epilogue_lds_core<EPI3, 4, 1>(
+          e3,
+          [&](int mi, int, float* p) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc3[mi][r];
+          },
+          patch, mb * M_HC, t_blk + t_w, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[a][r] = 0.f;
+    }
+    if (__any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
+  }
 }
 
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
   DC_REQUIRE(g.K == M_D && g.N % M_HC == 0 && g.N <= 1024 && g.Tp % M_BT == 0, "fused MLP: d_model 256, d_inner <= 1024");
   DC_REQUIRE(g.X == g.R && g.mean && g.rstd && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
-  if (g.gelu_tanh)
-    hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3((unsigned)(g.Tp / M_BT)), dim3(64 * M_NW), 0, st, g);
-  else
-    hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3((unsigned)(g.Tp / M_BT)), dim3(64 * M_NW), 0, st, g);
+  const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
+  if (g.Wp3) {
+    DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
+               "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
+    if (g.epi3 == EPI_BIAS) {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp_fused_kernel<true, EPI_BIAS>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((mlp_fused_kernel<false, EPI_BIAS>), grid, block, 0, st, g);
+    } else {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp_fused_kernel<true, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((mlp_fused_kernel<false, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
+    }
+  } else if (g.gelu_tanh) {
+    hipLaunchKernelGGL((mlp_fused_kernel<true, -1>), grid, block, 0, st, g);
+  } else {
+    hipLaunchKernelGGL((mlp_fused_kernel<false, -1>), grid, block, 0, st, g);
+  }
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -288,9 +288,12 @@ class HipModel:
         _lib.check(_lib.lib().dc_model_set_gemm_mode(self._h, {"f32": 0, "bf16x6": 1, "fp16x3": 2}[mode]))
         self.gemm_mode = mode
 
-    def set_mlp_fusion(self, on: bool):
-        """fp16x3: fc1 -> GELU -> fc2 as one kernel (default) or as two GEMM launches."""
-        _lib.check(_lib.lib().dc_model_set_mlp_fusion(self._h, int(bool(on))))
+    def set_mlp_fusion(self, level):
+        """fp16x3.  0 / False: fc1 and fc2 as two GEMM launches; 1: fc1 -> GELU -> fc2 as one kernel;
+        2 / True (default): that kernel also runs the GEMM that consumes LayerNorm(its output) -- the next
+        block's in_proj or the head's linear1."""
+        lvl = 2 if level is True else int(level)
+        _lib.check(_lib.lib().dc_model_set_mlp_fusion(self._h, lvl))
 
     def overflow(self) -> int:
         """fp16x3 range guard: workgroups that met an activation outside the fp16 range since the last call

@@ -246,12 +246,18 @@ int dc_model_filter(dc_model* m, void* stream, int32_t layer, int32_t seq_len, f
  * dc_model_overflow.  Default: 2; $DC_GEMM_MODE = "f32" | "bf16x6" | "fp16x3". */
 int dc_model_set_gemm_mode(dc_model* m, int32_t mode);
 
-/* fp16x3 only: run each block's MLP (fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics;
- * HyenaDNA block `mlp` + residual, see oracle/forward_ref.py backbone_forward) as ONE kernel that keeps the
- * d_inner-wide activation in registers (default on; needs d_model 256 and d_inner a multiple of 128, <= 1024,
- * otherwise -- and with on = 0 -- fc1 and fc2 run as two GEMM launches).  Same arithmetic either way
+/* fp16x3 only: kernel fusion level of the MLP half of each block (HyenaDNA block `mlp` + residual, see
+ * oracle/forward_ref.py backbone_forward).
+ *   0  fc1 and fc2 as two GEMM launches;
+ *   1  fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics as ONE kernel that keeps the d_inner-wide
+ *      activation in registers;
+ *   2  (default) that kernel also runs the GEMM that consumes LayerNorm(its output): the next block's in_proj,
+ *      or the head's linear1 (+ReLU + quality) after the last block -- the new residual stream is that GEMM's
+ *      B operand straight from the accumulator registers.
+ * Needs d_model 256, d_inner a multiple of 128 and <= 1024 (head_hidden a multiple of 128 for the head), otherwise
+ * the plain GEMM launches run.  Same arithmetic at every level
  * (tests/test_gpu_forward.py::test_mlp_fusion_matches_two_kernel_form). */
-int dc_model_set_mlp_fusion(dc_model* m, int32_t on);
+int dc_model_set_mlp_fusion(dc_model* m, int32_t level);
 
 /* fp16x3 range guard.  Mode 2 of dc_model_set_gemm_mode ("fp16x3") splits operands into two fp16 terms
  * (22 significant bits, three MFMAs); an activation whose magnitude exceeds 65504 cannot be represented
@@ -264,7 +270,7 @@ int dc_model_overflow(dc_model* m, void* stream, int32_t* count);
  * While enabled, every kernel launch of dc_forward / dc_forward_ragged is bracketed by an event
  * pair.  After synchronising the stream, dc_model_profile_get returns the summed milliseconds and
  * the number of launches of one stage since the last reset.  Stage names: "forward" (whole call),
- * "embed", "ln_stats", "gemm_inproj", "hyena", "gemm_outproj", "gemm_fc1", "gemm_fc2" (or "mlp_fused"),
+ * "embed", "ln_stats", "gemm_inproj", "hyena", "gemm_outproj", "gemm_fc1", "gemm_fc2" (or "mlp_fused" / "mlp_inproj_fused" / "mlp_head1_fused"),
  * "gemm_head1", "gemm_head2", "head_out".  bench.py builds its `roofline` object from these. */
 int dc_model_set_profiling(dc_model* m, int32_t enabled);
 int dc_model_profile_reset(dc_model* m);

@@ -203,21 +203,29 @@ def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     ids, q = _inputs(rng, 5, 333)
     d_ids, d_q = ops.to_device(ids), ops.to_device(q)
     model.set_profiling(True)
+    ran = lambda st, name: st.get(name, (0.0, 0))[1] > 0
+    takes = d_inner % 128 == 0
+    chained = model.forward(d_ids, d_q).cpu().numpy()  # default: MLP + the following GEMM in one kernel
+    st2 = model.profile()
+    assert ran(st2, "mlp_inproj_fused") == takes and ran(st2, "mlp_head1_fused") == takes
+    assert ran(st2, "gemm_head1") == (not takes) and st2.get("gemm_inproj", (0, 0))[1] == (0 if takes else 3)
+    model.profile_reset()
+    model.set_mlp_fusion(1)
     fused = model.forward(d_ids, d_q).cpu().numpy()
     stages = model.profile()
     model.profile_reset()
-    model.set_mlp_fusion(False)
+    model.set_mlp_fusion(0)
     plain = model.forward(d_ids, d_q).cpu().numpy()
     stages_plain = model.profile()
-    takes = d_inner % 128 == 0
-    ran = lambda st, name: st.get(name, (0.0, 0))[1] > 0
-    assert ran(stages, "mlp_fused") == takes and ran(stages, "gemm_fc1") == (not takes)
+    assert ran(stages, "mlp_fused") == takes and ran(stages, "gemm_fc1") == (not takes) and ran(stages, "gemm_head1")
     assert not ran(stages_plain, "mlp_fused") and ran(stages_plain, "gemm_fc1") and ran(stages_plain, "gemm_fc2")
     ref = fr.forward(sd, ids, q, fr.HyenaDNAConfig(d_inner=d_inner, gelu_approximate=gelu)).numpy()
+    _check(chained, ref)
     _check(fused, ref)
     _check(plain, ref)
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(fused - plain).max() < 5e-5 * scale  # same split arithmetic, different summation order only
+    assert np.abs(chained - plain).max() < 5e-5 * scale
     assert model.overflow() == 0
 
 
