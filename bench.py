@@ -31,6 +31,8 @@ FLOPS_PER_TOKEN = {
     "gemm_fc1": 2 * 256 * 1024,
     "gemm_fc2": 2 * 1024 * 256,
     "mlp_fused": 2 * 256 * 1024 + 2 * 1024 * 256,
+    "mlp_inproj_fused": 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 768,   # + the next block's in_proj
+    "mlp_head1_fused": 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 1024,   # + the head's linear1
     "gemm_head1": 2 * 256 * 1024,
     "gemm_head2": 2 * 1024 * 1024,
 }
@@ -41,6 +43,16 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 
 # padded token measured by the PMC passes committed under profiles/ ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950
 # correction applied) and the algorithmic bytes per token next to it.
 ROOFLINE_KERNELS = {
+    "mlp_inproj_fused": {
+        "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS> (fc1 -> GELU -> fc2 -> +residual -> LayerNorm -> next block's in_proj, fp16x3)",
+                   "traffic_bpt": 13826.2, "source": "profiles/r01_pmc_hbm_traffic_chain.json"},
+        "algorithmic_bpt": 2 * 1024 + 3 * 1024 + 16,  # residual stream in and out + in_proj output (fp32) + statistics
+    },
+    "mlp_head1_fused": {
+        "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS_RELU_Q> (last block's MLP + head linear1, fp16x3)",
+                   "traffic_bpt": 14800.9, "source": "profiles/r01_pmc_hbm_traffic_chain.json"},
+        "algorithmic_bpt": 2 * 1024 + 4 * 1024 + 20,
+    },
     "mlp_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true> (fc1 -> GELU -> fc2 -> +residual -> LN statistics, fp16x3)",
                    "traffic_bpt": 10692.42, "source": "profiles/r01_pmc_hbm_traffic_mlpfused.json"},
