@@ -229,10 +229,11 @@ def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     assert model.overflow() == 0
 
 
-@pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001)])
+@pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001), (1, 32769)])
 def test_forward_long_reads_match_oracle(env, B, L):
     """BASELINE configs 3 and 4: 2 kb reads and reads up to 10 kb (several 32-block output chunks of the
-    long-convolution kernel, filters longer than one LDS chunk)."""
+    long-convolution kernel, filters longer than one LDS chunk); 32 769 tokens = the longest sequence the
+    tokenizer emits (max_len_single_sentence + [SEP]), i.e. the full 32k filter."""
     torch, ops, sd, model = env
     from oracle import forward_ref as fr
 
