@@ -88,6 +88,11 @@ struct HyenaArgs {
   const float* ch_inv_scale;      // fp16x3: [D] 1 / (power-of-two scale of the channel's filter)
   int split_mode;                 // 0 = bf16x6, 1 = fp16x3
   int* overflow;                  // fp16x3 range guard counter
+  // layer 0 (hyena3 only): u is a function of the token id alone -- gather it from the per-id table instead
+  // of reading a materialised [3D][Tp] buffer (the embed kernel then does not write one)
+  const unsigned char* tok;       // [Tp] token id per packed slot, 255 = no token; nullptr = read `u`
+  const float* tab;               // [vocab][3D] in_proj(LayerNorm(emb[id])) (x0 | x1 | v)
+  int vocab;                      // <= 16
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
@@ -113,7 +118,8 @@ int launch_head_reduce(hipStream_t st, const float* part, int n_part, const floa
                        float* logits);
 int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
                     const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
-                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad);
+                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad,
+                    unsigned char* tok);  // u == nullptr: only x, qpad and the packed token ids `tok` are written
 int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
                     const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                     float* logits);

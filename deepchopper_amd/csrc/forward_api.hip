@@ -65,7 +65,7 @@ struct dc_model {
   int64_t weight_bytes = 0;
 
   // workspace (grown on demand)
-  DevBuf x, u, y, hmid, obuf, mean, rstd, qpad, idx, part;
+  DevBuf x, u, y, hmid, obuf, mean, rstd, qpad, idx, part, tok;
   int64_t Tp_cap = 0;
 
   // index arrays: host mirror of the last geometry + pinned staging
@@ -256,6 +256,7 @@ int ensure_workspace(dc_model* m, int64_t Tp) {
   if ((rc = ensure(m->mean, (size_t)Tp * f))) return rc;
   if ((rc = ensure(m->rstd, (size_t)Tp * f))) return rc;
   if ((rc = ensure(m->qpad, (size_t)Tp * f))) return rc;
+  if ((rc = ensure(m->tok, (size_t)Tp))) return rc;  // packed token ids for the layer-0 table gather
   if ((rc = ensure(m->part, (size_t)(c.head_hidden / 128) * Tp * 2 * f))) return rc;
   m->Tp_cap = Tp;
   return DC_OK;
@@ -511,10 +512,16 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   const bool fused_stats = !no_fused_stats && m->gemm_mode >= 1;
   static const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
   const bool l0_table = !no_l0_table && m->u_table0 != nullptr;
+  // layer 0 with the 16-bit long convolution: its kernel gathers u from the per-token-id table itself, so the
+  // embed kernel writes the packed token ids (1 B/token) instead of u (3 KB/token)
+  const bool l0_gather = l0_table && getenv("DC_NO_L0_GATHER") == nullptr && m->gemm_mode >= 1 && c.vocab <= 16 &&
+                         !(getenv("DC_HYENA") && atoi(getenv("DC_HYENA")) != 3);
+  unsigned char* tokp = (unsigned char*)m->tok.p;
   {
     ProfScope ps(m, st, "embed");
     rc = l0_table ? launch_embed_l0(st, d_ids, ids_i64, d_quals, m->emb, m->u_table0, c.vocab, D, m->d_blk_read,
-                                    m->d_toff, m->d_src_base, m->d_ntok, Tp, x, u, qpad)
+                                    m->d_toff, m->d_src_base, m->d_ntok, Tp, x, l0_gather ? nullptr : u, qpad,
+                                    l0_gather ? tokp : nullptr)
                   : launch_embed(st, d_ids, ids_i64, d_quals, m->emb, c.vocab, D, m->d_blk_read, m->d_toff,
                                  m->d_src_base, m->d_ntok, Tp, x, qpad);
     if (rc) return rc;
@@ -565,6 +572,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.ch_inv_scale = L.kinv;
       a.split_mode = m->gemm_mode == 2 ? 1 : 0;
       a.overflow = m->d_overflow;
+      if (li == 0 && l0_gather) {
+        a.tok = tokp;
+        a.tab = m->u_table0;
+        a.vocab = c.vocab;
+      }
       ProfScope ps(m, st, "hyena");
       // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
       static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;

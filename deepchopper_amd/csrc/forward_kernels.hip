@@ -2092,7 +2092,8 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
   return DC_OK;
 }
 
-template <int CB, int MODE>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16
+template <int CB, int MODE, bool TAB>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16;
+                                       // TAB: u gathered from the layer-0 table by token id (HyenaArgs::tok / tab)
 #ifndef DC_H3_OCC
 #define DC_H3_OCC 2
 #endif
@@ -2102,6 +2103,7 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   constexpr int NP = SM::NP;
   constexpr int H3_FILT_BYTES = h3_filt_bytes(NP), H3_ZBUF_BYTES = h3_zbuf_bytes(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_h3[];
+  __shared__ float s_tab3[3 * 17];  // TAB: x0 | x1 | v of this channel for token ids 0..15, entry 16 = 0 (no token)
   constexpr int NACC = CB / 4;
   DC_STAMP_T(st0);
   const int g = blockIdx.x, c = blockIdx.y, oc = blockIdx.z;
@@ -2130,8 +2132,31 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
               bx1 = a.sb[a.D + c];
   const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
               wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
+  const unsigned char* tkz = TAB ? a.tok + z_off : nullptr;
+  if (TAB) {
+    if (tid < 3 * 17) {
+      const int k3 = tid / 17, id = tid - 17 * k3;
+      s_tab3[tid] = id < a.vocab && id < 16 ? a.tab[(int64_t)id * 3 * a.D + k3 * a.D + c] : 0.f;
+    }
+    // (made visible by the barrier in front of the first z tile)
+  }
+  auto tab_at = [&](int k3, uint32_t ids, int byte) -> float {
+    const uint32_t id = (ids >> (8 * byte)) & 255u;
+    return s_tab3[k3 * 17 + (id < 16u ? id : 16u)];
+  };
   auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
     l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TAB) {  // the token ids of positions t-4 .. t+3 travel in l1.x / c1.x; z_store looks the values up
+      uint32_t il = 0xFFFFFFFFu, ic = 0xFFFFFFFFu;
+      if (p < z_nblk) {
+        const int64_t t = 32 * p + zq4;
+        if (t > 0) il = *reinterpret_cast<const uint32_t*>(tkz + t - 4);
+        ic = *reinterpret_cast<const uint32_t*>(tkz + t);
+      }
+      l1.x = __builtin_bit_cast(float, il);
+      c1.x = __builtin_bit_cast(float, ic);
+      return;
+    }
     if (p < z_nblk) {
       const int64_t t = 32 * p + zq4;
       if (t > 0) {
@@ -2143,7 +2168,15 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
     }
   };
   bool ovf = false;  // fp16x3: a z value left the fp16 range
-  auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
+  auto z_store = [&](int p, const float4& l1_, const float4& c1_, const float4& lv_, const float4& cv_) {
+    float4 l1 = l1_, c1 = c1_, lv = lv_, cv = cv_;
+    if (TAB) {
+      const uint32_t il = __builtin_bit_cast(uint32_t, l1_.x), ic = __builtin_bit_cast(uint32_t, c1_.x);
+      l1 = make_float4(0.f, 0.f, tab_at(1, il, 2), tab_at(1, il, 3));
+      lv = make_float4(0.f, 0.f, tab_at(2, il, 2), tab_at(2, il, 3));
+      c1 = make_float4(tab_at(1, ic, 0), tab_at(1, ic, 1), tab_at(1, ic, 2), tab_at(1, ic, 3));
+      cv = make_float4(tab_at(2, ic, 0), tab_at(2, ic, 1), tab_at(2, ic, 2), tab_at(2, ic, 3));
+    }
     float z[4];
     z[0] = fmaf(wx1_0, l1.z, fmaf(wx1_1, l1.w, fmaf(wx1_2, c1.x, bx1))) * fmaf(wv_0, lv.z, fmaf(wv_1, lv.w, fmaf(wv_2, cv.x, bv)));
     z[1] = fmaf(wx1_0, l1.w, fmaf(wx1_1, c1.x, fmaf(wx1_2, c1.y, bx1))) * fmaf(wv_0, lv.w, fmaf(wv_1, cv.x, fmaf(wv_2, cv.y, bv)));
@@ -2278,11 +2311,35 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
   // x0 windows are requested one output block ahead of their use: fetched when needed, each of the (up to) eight
   // blocks of a wave paid a full memory round trip (a quarter of the kernel was this epilogue)
+  const unsigned char* tke = TAB ? a.tok + e_off : nullptr;
+  // TAB: a window is 5 dwords of token ids (positions t0-4 .. t0+15), expanded through the table at its use
+  auto load_win = [&](int64_t t0, bool has_prev, bool active, float (&w)[20]) {
+    if (!TAB) {
+      load_window20(ux0, t0, has_prev, active, w);
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      uint32_t ids = 0xFFFFFFFFu;
+      if (active && (j > 0 || has_prev)) ids = *reinterpret_cast<const uint32_t*>(tke + t0 - 4 + 4 * j);
+      w[j] = __builtin_bit_cast(float, ids);
+    }
+  };
+  auto expand_win = [&](float (&w)[20]) {
+    if (!TAB) return;
+    uint32_t ids[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ids[j] = __builtin_bit_cast(uint32_t, w[j]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) w[4 * j + b] = tab_at(0, ids[j], b);
+  };
   float wq[2][20];
   {
     const int pp0 = p_out0 + wave;
     const int64_t t00 = 32 * pp0 + eh;
-    load_window20(ux0, t00, t00 > 0, pp0 <= p_out_last && pp0 < e_nblk, wq[0]);
+    load_win(t00, t00 > 0, pp0 <= p_out_last && pp0 < e_nblk, wq[0]);
   }
 #pragma unroll
   for (int m = 0; m < NACC; ++m) {
@@ -2290,14 +2347,15 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
     if (m + 1 < NACC) {
       const int ppn = pp + 4;
       const int64_t tn = 32 * ppn + eh;
-      load_window20(ux0, tn, true, ppn <= p_out_last && ppn < e_nblk, wq[(m + 1) & 1]);
+      load_win(tn, true, ppn <= p_out_last && ppn < e_nblk, wq[(m + 1) & 1]);
     }
     if (pp <= p_out_last) {  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r32] = acc[m][e];
       if (pp < e_nblk) {
         const int64_t t0 = 32 * pp + eh;
-        const float(&w)[20] = wq[m & 1];
+        float(&w)[20] = wq[m & 1];
+        expand_win(w);
         float o[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -2322,22 +2380,22 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
 #endif
 }
 
-template <int MODE>
+template <int MODE, bool TAB>
 static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
   static bool attr_set = false;
   if (!attr_set) {
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE>),
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE, TAB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE>),
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE, TAB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   static const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
   if (max_P <= 32 && !cb16) {
-    hipLaunchKernelGGL((hyena3_kernel<32, MODE>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
   } else {
-    hipLaunchKernelGGL((hyena3_kernel<16, MODE>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<16, MODE, TAB>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
   }
   DC_LAUNCH_CHECK();
   return DC_OK;
@@ -2345,11 +2403,13 @@ static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int
 
 int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   DC_REQUIRE(a.kfp && a.kfp_nu == hyena3_units(a.kf_taps), "hyena3 needs the 16-bit filter planes");
+  const bool tab = a.tok != nullptr;
+  if (tab) DC_REQUIRE(a.tab && a.vocab >= 1 && a.vocab <= 16, "hyena3 table gather needs the layer-0 table and vocab <= 16");
   if (a.split_mode == 1) {
     DC_REQUIRE(a.kfp_f16 && a.ch_inv_scale && a.overflow, "fp16x3 long convolution needs its planes / scales / guard");
-    return launch_hyena3_t<1>(st, a, n_groups, max_P);
+    return tab ? launch_hyena3_t<1, true>(st, a, n_groups, max_P) : launch_hyena3_t<1, false>(st, a, n_groups, max_P);
   }
-  return launch_hyena3_t<0>(st, a, n_groups, max_P);
+  return tab ? launch_hyena3_t<0, true>(st, a, n_groups, max_P) : launch_hyena3_t<0, false>(st, a, n_groups, max_P);
 }
 
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
@@ -2439,12 +2499,13 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
                                                        const int64_t* __restrict__ src_base,
                                                        const int32_t* __restrict__ ntok, int64_t Tp,
                                                        float* __restrict__ x, float* __restrict__ u,
-                                                       float* __restrict__ qpad) {
+                                                       float* __restrict__ qpad, unsigned char* __restrict__ tok) {
   extern __shared__ float s_tab[];  // [vocab][D] then [vocab][3D]
   float* s_emb = s_tab;
   float* s_u = s_tab + vocab * D;
   for (int j = threadIdx.x; j < vocab * D; j += 256) s_emb[j] = emb[j];
-  for (int j = threadIdx.x; j < vocab * 3 * D; j += 256) s_u[j] = u_table[j];
+  if (u)
+    for (int j = threadIdx.x; j < vocab * 3 * D; j += 256) s_u[j] = u_table[j];
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
@@ -2462,21 +2523,24 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
   }
   qpad[t] = qv;
   for (int c = 0; c < D; ++c) x[(int64_t)c * Tp + t] = id >= 0 ? s_emb[id * D + c] : 0.f;
-  for (int c = 0; c < 3 * D; ++c) u[(int64_t)c * Tp + t] = id >= 0 ? s_u[id * 3 * D + c] : 0.f;
+  if (tok) tok[t] = id >= 0 ? (unsigned char)id : (unsigned char)255;
+  if (u)
+    for (int c = 0; c < 3 * D; ++c) u[(int64_t)c * Tp + t] = id >= 0 ? s_u[id * 3 * D + c] : 0.f;
 }
 
 int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
                     const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
-                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad) {
+                    const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad,
+                    unsigned char* tok) {
   const unsigned grid = (unsigned)((Tp + 255) / 256);
   const size_t lds = (size_t)vocab * D * 4 * sizeof(float);
   DC_REQUIRE(lds <= 64 * 1024, "embedding tables do not fit the default LDS allocation");
   if (ids_i64)
     hipLaunchKernelGGL(embed_l0_kernel<int64_t>, dim3(grid), dim3(256), lds, st, (const int64_t*)ids, quals, emb,
-                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad);
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok);
   else
     hipLaunchKernelGGL(embed_l0_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)ids, quals, emb,
-                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad);
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -298,3 +298,30 @@ def test_fp16x3_range_guard_and_fallback(hip_lib):
     assert np.isfinite(got).all() and model.net.gemm_mode == "fp16x3"
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(got - ref).max() < 2e-4 * scale
+
+
+def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
+    """Layer 0's in_proj output is a function of the token id alone; by default the long-convolution kernel gathers
+    it from the 16-row table instead of reading a materialised [3D][T] buffer.  Both forms see the same fp32
+    values, so the logits must be identical to the last bit (fixed-length and ragged batches, pad tokens, [UNK])."""
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+
+    sd = synthetic_state_dict(21)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    rng = np.random.default_rng(21)
+    ids, q = _inputs(rng, 6, 777)
+    ids[0, :40] = 4   # left-pad tokens run through the model in reference padding
+    ids[1, 100] = 6   # [UNK]
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    first = np.array([0, 5, 100, 333, 0, 776 - 31], np.int32)
+    ntok = (777 - first).astype(np.int32)
+    outs = {}
+    for gather in (True, False):
+        if gather:
+            monkeypatch.delenv("DC_NO_L0_GATHER", raising=False)
+        else:
+            monkeypatch.setenv("DC_NO_L0_GATHER", "1")
+        outs[gather] = (model.forward(d_ids, d_q).cpu().numpy(), model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy())
+    assert np.array_equal(outs[True][0], outs[False][0])
+    assert np.array_equal(outs[True][1], outs[False][1])
