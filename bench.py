@@ -105,6 +105,63 @@ def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
     return n / total, n, torch.get_num_threads(), res
 
 
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start N workers (one per GPU, the environment
+    torch.distributed.run would give them), let them run the normal N-rank path (barrier, max over ranks) and
+    print rank 0's line.  DC_BENCH_SHARE_GPU=1 rehearses this on a one-GPU box: every worker uses device 0 and
+    the process group runs on gloo."""
+    from deepchopper_amd import launcher
+
+    share = os.environ.get("DC_BENCH_SHARE_GPU") == "1"
+    extra = {"DC_BENCH_BACKEND": "gloo"} if share else {}
+    procs = launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, share_gpu=share,
+                                 extra_env=extra)
+    outs = launcher.wait_ranks(procs)
+    line = launcher.last_json_line(outs[0])
+    line["launcher"] = "self (one subprocess per GPU)"
+    print(json.dumps(line))
+
+
+def file_e2e_leg(pipe, n_reads: int, read_len: int, batch: int) -> dict:
+    """FASTQ-inclusive rate (SURVEY 8d's metric is "FASTQ bytes in -> labels + intervals out"): `n_reads` synthetic
+    reads written to a FASTQ file, then file -> native reader -> pinned staging -> H2D -> tokenise / forward /
+    smooth -> D2H of labels + intervals through `predict_stream`.  An extra key of the bench line, not `value`."""
+    import tempfile
+
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader
+
+    tmp = tempfile.mkdtemp(prefix="dc_bench_")
+    path = os.path.join(tmp, "reads.fq")
+    with open(path, "wb") as fh:
+        for b0 in range(0, n_reads, 10_000):
+            n = min(10_000, n_reads - b0)
+            seq, qual, ids = synth.synth_reads_fixed(n, read_len, seed=42 + b0, start_index=b0)
+            fh.write(synth.to_fastq(seq, qual, ids))
+    try:
+        cap = batch * (read_len + 1)
+        with FastqReader(path) as rd:  # warm-up: pinned staging, copy stream
+            for i, _ in enumerate(pipe.predict_stream(rd.chunks(batch, cap))):
+                if i >= 1:
+                    break
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = n_iv = 0
+        with FastqReader(path) as rd:
+            for res in pipe.predict_stream(rd.chunks(batch, cap)):
+                n += len(res["names"])
+                n_iv += int(res["n_intervals"].sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        os.remove(path)
+        os.rmdir(tmp)
+    return {"value": round(n / dt, 1), "unit": "reads/s", "reads": n, "seconds": round(dt, 3), "container": "plain FASTQ",
+            "what": "file -> parse -> H2D -> tokenise/forward/smooth -> D2H labels + intervals (predict_stream)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,16 +173,20 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "fp16x3"], default=os.environ.get("DC_GEMM_MODE", "fp16x3"))
+    ap.add_argument("--strict-steps", type=int, default=5, help="extra untimed-in-`value` leg in the strict fp32-equivalent "
+                    "mode (bf16x6) -> `value_bf16x6` (0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=100_000, help="FASTQ-inclusive leg through predict_stream -> `file_e2e` "
+                    "(N = 1 only; 0 = skip)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)  # parent: starts one worker per GPU before anything here touches the GPU
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     # one rank per GPU; DC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code
     # path on a one-GPU box (ranks then share the device)
     backend = os.environ.get("DC_BENCH_BACKEND", "nccl")
@@ -188,6 +249,30 @@ def main():
     fp16_overflow = model.net.overflow() if args.gemm_mode == "fp16x3" else 0  # range guard of the fp16 split
     prof = model.net.profile() if not args.no_profile else {}
     model.net.set_profiling(False)
+    per_rank_s = [elapsed]
+    if world > 1:
+        own = time.perf_counter() - t0  # not comparable across ranks to better than the barrier; informational
+        gathered = [None] * world
+        dist.all_gather_object(gathered, round(own, 6))
+        per_rank_s = gathered
+
+    # strict fp32-equivalent arithmetic (error-free 3-way bf16 split), same config, a few steps: so that the
+    # driver's record also carries the throughput of the mode that needs no range guard
+    strict = None
+    if args.strict_steps > 0 and args.gemm_mode != "bf16x6":
+        model.net.set_gemm_mode("bf16x6")
+        step(0)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for j in range(args.strict_steps):
+            step(j)
+        torch.cuda.synchronize()
+        barrier()
+        dt = dist_max(time.perf_counter() - t1, device="cuda" if backend == "nccl" else "cpu")
+        strict = {"value": round(world * B * args.strict_steps / dt, 2), "steps": args.strict_steps,
+                  "ms_per_step": round(dt / args.strict_steps * 1e3, 3)}
+        model.net.set_gemm_mode(args.gemm_mode)
 
     if rank == 0:
         tokens_per_launch = B * (L + 1)
@@ -219,6 +304,7 @@ def main():
             if "traffic_bpt" in mode:
                 padded = -(-(B * (-(-(L + 1) // 32) * 32)) // 256) * 256  # reads start at multiples of 32 token slots
                 roof["traffic"] = int(mode["traffic_bpt"] * padded)
+                roof["traffic_kind"] = "constant from the committed PMC profile (bytes per padded token x this launch's tokens), not measured in this run"
                 roof["traffic_source"] = mode["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                 roof["algorithmic_hbm_bytes_per_launch"] = int(padded * info["algorithmic_bpt"])
             if args.gemm_mode in ("bf16x6", "fp16x3"):
@@ -259,6 +345,9 @@ def main():
             f1 = {"per_base_f1_vs_oracle": round(2 * tp / max(2 * tp + fp + fn, 1), 6), "reads": n_done,
                   "intervals_identical": bool(same_iv)}
 
+        e2e = None
+        if world == 1 and args.e2e_reads > 0:
+            e2e = file_e2e_leg(pipe, args.e2e_reads, L, B)
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",
@@ -279,6 +368,10 @@ def main():
                        "reads_per_step_per_gpu": B, "read_len": L, "tokens_per_read": L + 1,
                        "parallelism": f"read-sharded x{world}, no collectives"},
             "roofline": roof,
+            "value_bf16x6": strict["value"] if strict else None,
+            "bf16x6_leg": strict,
+            "file_e2e": e2e,
+            "per_rank_seconds": per_rank_s,
             "cpu_baseline": cpu,
             "parity": f1,
             "fp16_overflow_events": fp16_overflow,

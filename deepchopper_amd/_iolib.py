@@ -21,6 +21,7 @@ _SIGNATURES = {
     "dc_fq_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
     "dc_fq_open_range": (C.c_int, [C.c_char_p, i64, i64, C.c_int, C.POINTER(vp)]),
     "dc_fq_read_chunk": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp, C.POINTER(i64)]),
+    "dc_fq_read_chunk_full": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
     "dc_fq_records_read": (i64, [vp]),
     "dc_fq_bytes_consumed": (i64, [vp]),
     "dc_fq_close": (None, [vp]),
@@ -28,7 +29,14 @@ _SIGNATURES = {
     "dc_bgzf_write": (C.c_int, [vp, vp, i64]),
     "dc_bgzf_write_fastq": (C.c_int, [vp, i64, vp, vp, vp, vp, vp]),
     "dc_bgzf_close": (C.c_int, [vp]),
+    "dc_chop_write_chunk": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, vp,
+                                      C.POINTER(i64)]),
 }
+
+
+class ChopParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("min_read_len", "max_process_intervals", "min_read_length_after_chop",
+                                         "chop_type", "output_chopped_seqs", "id_annotation")]
 
 _lib = None
 

@@ -82,11 +82,14 @@ _SIGNATURES = {
     "dc_model_free": (None, [vp]),
     "dc_forward": (C.c_int, [vp, vp, vp, i32, vp, i32, i32, vp]),
     "dc_forward_ragged": (C.c_int, [vp, vp, vp, i32, vp, i32, i64, C.POINTER(i32), C.POINTER(i32), vp]),
+    "dc_head_forward": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "dc_model_device_bytes": (i64, [vp]),
     "dc_model_filter": (C.c_int, [vp, vp, i32, i32, vp]),
     "dc_model_set_gemm_mode": (C.c_int, [vp, i32]),
     "dc_model_set_mlp_fusion": (C.c_int, [vp, i32]),
     "dc_model_overflow": (C.c_int, [vp, vp, C.POINTER(i32)]),
+    "dc_model_set_overflow_target": (C.c_int, [vp, vp]),
+    "dc_model_get_gemm_mode": (C.c_int, [vp, C.POINTER(i32)]),
     "dc_model_set_profiling": (C.c_int, [vp, i32]),
     "dc_model_profile_reset": (C.c_int, [vp]),
     "dc_model_profile_get": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),

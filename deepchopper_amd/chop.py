@@ -1,9 +1,15 @@
-"""`deepchopper chop` driver: consumer of the predict -> chop wire format.
+"""`deepchopper chop` in two forms.
 
-Reference: `deepchopper-chop` = src/bin/predict.rs:130-384 (process_chunk + main) with
-output/split.rs:60-226 for the record splitting.  Per 10 000-read chunk the per-read work of the
-reference's `par_iter` (majority vote -> regions -> filter -> complement) is ONE fused GPU launch
-(`dc_smooth_intervals_from_labels`); the host only slices byte strings and writes records.
+* `chop(...)`: consumer of the reference's predict -> chop wire format, `deepchopper-chop` =
+  src/bin/predict.rs:130-384 (process_chunk + main) with output/split.rs:60-226 for the record splitting.
+  Per 10 000-read chunk the per-read work of the reference's `par_iter` (majority vote -> regions -> filter ->
+  complement) is ONE fused GPU launch (`dc_smooth_intervals_from_labels`).
+* `predict_chop(...)`: the fused streaming flow FASTQ(.gz) -> predict -> chop -> BGZF with no `.pt` in between
+  (the 28 B/token wire format is ~280 GB for 5 M nanopore reads): `PredictPipeline.predict_stream` leaves every
+  batch's intervals / kept segments on the host, and `dc_chop_write_chunk` (include/deepchopper_io.h) applies the
+  same gating and record splitting natively, straight from the reader's packed chunk into the BGZF writer.
+
+Both produce the same bytes for the same predictions (tests/test_gpu_pipeline.py).
 """
 from __future__ import annotations
 
@@ -11,11 +17,20 @@ import os
 
 import numpy as np
 
-from . import ops, rs_api
-from .fastq import BgzfWriter, iter_fastq
+from . import _iolib, ops, rs_api
+from .fastq import BgzfWriter, FastqReader
 from .predict import SmoothParams
 
 CHOP_TYPES = ("terminal", "internal", "all")
+
+
+def chop_params(sp: SmoothParams, chop_type: str = "all", output_chopped_seqs: bool = False) -> "_iolib.ChopParams":
+    if chop_type not in CHOP_TYPES:
+        raise ValueError("Invalid chop type")
+    return _iolib.ChopParams(min_read_len=sp.min_read_len, max_process_intervals=sp.max_process_intervals,
+                             min_read_length_after_chop=sp.min_read_length_after_chop,
+                             chop_type=CHOP_TYPES.index(chop_type), output_chopped_seqs=int(output_chopped_seqs),
+                             id_annotation=1)
 
 
 def split_record_by_remove_intervals(seq: bytes, rid: bytes, qual: bytes, keep: list[tuple[int, int]],
@@ -35,20 +50,25 @@ def split_record_by_remove_intervals(seq: bytes, rid: bytes, qual: bytes, keep: 
     return parts
 
 
-def chop_chunk(records, predicts: dict, sp: SmoothParams, chop_type: str = "all"):
-    """process_chunk (src/bin/predict.rs:130-192, `--ocq` off).  records: [(name, seq, qual)]."""
-    todo, out_slots = [], []
+def split_record_by_intervals(seq: bytes, rid: bytes, qual: bytes, intervals: list[tuple[int, int]]):
+    """split_noodle_records_by_intervals (output/split.rs:138-169), the `--ocq` form: the chopped segments."""
+    return [(rid + b"|%d:%d" % (s, e), seq[s:e], qual[s:e]) for s, e in intervals]
+
+
+def chop_chunk(records, predicts: dict, sp: SmoothParams, chop_type: str = "all", output_chopped_seqs: bool = False):
+    """process_chunk (src/bin/predict.rs:130-192).  records: [(name, header, seq, qual)], `header` = the whole
+    definition line (records that pass through keep their description, as fq_record.clone() does)."""
+    todo = []
     out: list[list] = []
-    for name, seq, qual in records:
+    for name, header, seq, qual in records:
         p = predicts.get(name)
         if p is None:
             continue  # records without predictions are skipped
         slot = len(out)
-        out.append([(name.encode(), seq, qual)])
+        out.append([(header.encode("latin1"), seq, qual)])
         if p.seq_len() < sp.min_read_len:
             continue
         todo.append((slot, p, name, qual))
-        out_slots.append(slot)
     if todo:
         labels = [np.asarray(p.prediction, dtype=np.int8).tobytes() for _, p, _, _ in todo]
         lab, offs = ops.pack_reads(labels)
@@ -56,6 +76,7 @@ def chop_chunk(records, predicts: dict, sp: SmoothParams, chop_type: str = "all"
                                                min_interval=sp.min_interval, approved=sp.approved,
                                                max_intervals=max(sp.approved, 1), want_smooth=False)
         niv = res["n_intervals"].cpu().numpy()
+        iv = res["intervals"].cpu().numpy()
         keep = res["keep"].cpu().numpy()
         nkeep = res["n_keep"].cpu().numpy()
         for k, (slot, p, name, qual) in enumerate(todo):
@@ -63,15 +84,31 @@ def chop_chunk(records, predicts: dict, sp: SmoothParams, chop_type: str = "all"
                 continue
             if p.seq_len() != len(qual):
                 continue  # truncated prediction: do not process (predict.rs:160-164)
-            segs = [tuple(x) for x in keep[k, : nkeep[k]].tolist()]
-            out[slot] = split_record_by_remove_intervals(p.seq.encode(), name.encode(), qual, segs,
-                                                         sp.min_read_length_after_chop, True, chop_type)
+            if output_chopped_seqs:
+                out[slot] = split_record_by_intervals(p.seq.encode(), name.encode("latin1"), qual,
+                                                      [tuple(x) for x in iv[k, : niv[k]].tolist()])
+            else:
+                segs = [tuple(x) for x in keep[k, : nkeep[k]].tolist()]
+                out[slot] = split_record_by_remove_intervals(p.seq.encode(), name.encode("latin1"), qual, segs,
+                                                             sp.min_read_length_after_chop, True, chop_type)
     return [r for recs in out for r in recs]
+
+
+def _final_name(fq: str, output_prefix: str | None, n_predictions: int, n_records: int) -> str:
+    """`{prefix or fastq stem}.{n_predictions}pd.{n_records}record.chop.fq.gz` (predict.rs:343-356; file_stem
+    strips one extension, the file lands in the working directory when no prefix is given)."""
+    stem = output_prefix or os.path.splitext(os.path.basename(fq))[0]
+    return f"{stem}.{n_predictions}pd.{n_records}record.chop.fq.gz"
+
+
+def _temp_name(fq: str, output_prefix: str | None, tag: str = "") -> str:
+    out_dir = os.path.dirname(os.path.abspath(output_prefix or fq)) or "."  # same filesystem as the output (predict.rs:252-266)
+    return os.path.join(out_dir, f".deepchopper_temp_{os.getpid()}{tag}.fq.gz")
 
 
 def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_type: str = "all",
          output_prefix: str | None = None, chunk_size: int = 10000, max_batch_size: int | None = None,
-         threads: int = 2) -> str:
+         threads: int = 2, output_chopped_seqs: bool = False) -> str:
     """main() of src/bin/predict.rs:197-384.  Returns the output path
     `{prefix or fastq stem}.{n_predictions}pd.{n_records}record.chop.fq.gz` -- a BGZF stream written by
     `threads` compression workers, as the reference's bgzf::io::MultithreadedWriter (predict.rs:266-270)."""
@@ -81,33 +118,92 @@ def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_
     predicts: dict = {}
     for d in predict_dirs:
         predicts.update(rs_api.load_predicts_from_batch_pts(d, rs_api.IGNORE_LABEL, max_batch_size))
-    out_dir = os.path.dirname(os.path.abspath(output_prefix or fq)) or "."
-    tmp = os.path.join(out_dir, f".deepchopper_temp_{os.getpid()}.fq.gz")
-    n_out = 0
+    tmp = _temp_name(fq, output_prefix)
+    n_out = n_in = 0
     try:
-        with BgzfWriter(tmp, threads=threads) as fh:
-            chunk = []
-
-            def flush():
-                nonlocal n_out
-                for rid, seq, qual in chop_chunk(chunk, predicts, sp, chop_type):
+        with BgzfWriter(tmp, threads=threads) as fh, FastqReader(fq, full_header=True) as rd:
+            for c in rd.chunks(chunk_size, 64 << 20):
+                names = c.names()
+                hdr, ho = c._names.tobytes(), c._name_offsets
+                s, q, o = c.seq.tobytes(), c.qual.tobytes(), c.offsets
+                recs = [(names[i], hdr[ho[i]: ho[i + 1]].decode("latin1"), s[o[i]: o[i + 1]], q[o[i]: o[i + 1]])
+                        for i in range(c.n)]
+                n_in += c.n
+                for rid, seq, qual in chop_chunk(recs, predicts, sp, chop_type, output_chopped_seqs):
                     fh.write_record(rid, seq, qual)
                     n_out += 1
-                chunk.clear()
-
-            for rec in iter_fastq(fq):
-                chunk.append(rec)
-                if len(chunk) >= chunk_size:
-                    flush()
-            if chunk:
-                flush()
-        stem = output_prefix or os.path.splitext(os.path.basename(fq))[0]
-        final = f"{stem}.{len(predicts)}pd.{n_out}record.chop.fq.gz"
-        if not os.path.isabs(final) and output_prefix is None:
-            final = os.path.join(os.getcwd(), final)
+        if n_in == 0:
+            raise ValueError(f"No valid records found in {fq}")
+        final = _final_name(fq, output_prefix, len(predicts), n_out)
         os.replace(tmp, final)
     except Exception:
         if os.path.exists(tmp):
             os.remove(tmp)
         raise
     return final
+
+
+def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all", output_chopped_seqs: bool = False,
+                        on_batch=None) -> tuple[int, int]:
+    """The fused flow on an open writer: every chunk goes FASTQ bytes -> tokenise -> forward -> smoothing ->
+    intervals on the GPU, then gating + splitting + BGZF on the host library.  Chunks must come from a reader
+    opened with full_header=True.  Returns (reads predicted, records written)."""
+    params = chop_params(pipe.smooth, chop_type, output_chopped_seqs)
+    n_reads = n_out = 0
+    for res in pipe.predict_stream(chunks, want_labels=False, borrow=True, want_names=False):
+        n = int(res["lengths"].shape[0])
+        n_out += writer.chop_write_chunk(params, n, res["headers"], res["header_offsets"], res["name_len"], res["seq"],
+                                         res["qual"], res["in_offsets"], res["pred_len"], res["n_intervals"],
+                                         res["intervals"], res["n_keep"], res["keep"])
+        n_reads += n
+        if on_batch is not None:
+            on_batch(res)
+    return n_reads, n_out
+
+
+def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | None = None, threads: int = 2,
+                 output_chopped_seqs: bool = False, max_reads: int = 8192, max_tokens: int = 2_000_000,
+                 chunks=None, level: int = 6, part_path: str | None = None):
+    """`deepchopper predict` + `deepchopper chop` as one streaming pass (no `.pt` files).
+
+    Output naming and the temp-file-then-rename protocol are the chop binary's (predict.rs:252-366).  With
+    `part_path` (multi-GPU workers) the records go to that file instead and nothing is renamed: the parent
+    concatenates the per-rank BGZF parts.  Returns (path, reads, records)."""
+    if chop_type not in CHOP_TYPES:
+        raise ValueError("Invalid chop type")
+    tmp = part_path or _temp_name(fq, output_prefix)
+    try:
+        with BgzfWriter(tmp, threads=threads, level=level) as fh:
+            if chunks is None:
+                with FastqReader(fq, full_header=True) as rd:
+                    n_reads, n_out = predict_chop_stream(pipe, rd.chunks(max_reads, max_tokens), fh, chop_type,
+                                                         output_chopped_seqs)
+            else:
+                n_reads, n_out = predict_chop_stream(pipe, chunks, fh, chop_type, output_chopped_seqs)
+        if part_path:
+            return tmp, n_reads, n_out
+        if n_reads == 0:
+            raise ValueError(f"No valid records found in {fq}")
+        final = _final_name(fq, output_prefix, n_reads, n_out)
+        os.replace(tmp, final)
+    except Exception:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise
+    return final, n_reads, n_out
+
+
+def merge_bgzf_parts(parts: list[str], final: str) -> None:
+    """Concatenate per-rank BGZF outputs: a BGZF file is a series of independent gzip members, so the byte-wise
+    concatenation (each part's 28-byte EOF block is an empty member) is again a valid BGZF / gzip stream."""
+    with open(final + ".tmp", "wb") as out:
+        for p in parts:
+            with open(p, "rb") as fh:
+                while True:
+                    b = fh.read(8 << 20)
+                    if not b:
+                        break
+                    out.write(b)
+    os.replace(final + ".tmp", final)
+    for p in parts:
+        os.remove(p)

@@ -1,42 +1,52 @@
-"""`deepchopper predict` command line (deepchopper/cli.py:66-152) on the HIP hot path.
+"""`deepchopper predict` / `deepchopper chop` command line (deepchopper/cli.py:66-170) on the HIP hot path.
 
     python -m deepchopper_amd.cli predict reads.fastq -g 1 -o predictions -b 12 -m /path/to/checkpoint
+    python -m deepchopper_amd.cli predict reads.fastq.gz -g 8 --chop -m /path/to/checkpoint     # fused predict -> chop
+    python -m deepchopper_amd.cli chop predictions/0 reads.fastq
 
 Flags and defaults are the reference's (`--gpus/-g 0`, `--output/-o predictions`, `--batch-size/-b 12`,
 `--workers/-w 0`, `--model/-m rna002`, `--limit-batches`, `--max-sample`, `--verbose/-v`).  Differences:
 there is no CPU mode (`-g 0` is rejected: this build has no CPU fallback) and `-m` also accepts a local
 checkpoint path because the Hub is unreachable here.  Output: `{out}/0/{rank}_{batch}.pt` in the
 reference's CustomWriter format (callbacks.py:12-25), which the reference's `deepchopper chop`
-consumes unchanged; `--native` additionally writes per-read labels / intervals (`{rank}.intervals.tsv`).
+consumes unchanged; `--native` additionally writes per-read labels / intervals (`{rank}.intervals.tsv`);
+`--chop` runs predict and chop as one streaming pass and writes `{stem}.{n}pd.{m}record.chop.fq.gz` with no
+`.pt` files in between.
+
+`--gpus N` (N > 1) starts one worker process per GPU itself, as the reference does through Lightning
+(cli.py:126-147); it also runs under `python -m torch.distributed.run --nproc-per-node N` (a worker sees the
+same environment either way).
 """
 from __future__ import annotations
 
 import argparse
+import json
 import logging
 import os
 import sys
 from pathlib import Path
 
-import numpy as np
-
 from .fastq import FastqReader, check_compressed_type, shard_byte_range
 
 
-def rank_chunks(path: str, rank: int, world: int, max_reads: int, max_bases: int, max_sample: int | None = None):
+def rank_chunks(path: str, rank: int, world: int, max_reads: int, max_bases: int, max_sample: int | None = None,
+                full_header: bool = False):
     """This rank's reads as FastqChunks, streamed (never the whole file in memory).
 
     Uncompressed and BGZF input: one contiguous byte-range shard per rank, so a rank never
-    parses -- or inflates -- another rank's reads.  Plain gzip cannot be entered mid-stream: every rank
-    inflates the file and keeps every world-th chunk (chunk boundaries depend only on the file and the
-    limits, so ranks agree on them).  `max_sample` (the reference's --max-sample: the first N records of
-    the file) also uses the round-robin form because it needs global record numbers."""
+    parses -- or inflates -- another rank's reads.  Plain gzip cannot be entered mid-stream: under the
+    command's own launcher the parent inflates the file once and deals chunks to the workers
+    (launcher.ChunkFeeder); under an external launcher every rank inflates the file and keeps every
+    world-th chunk (chunk boundaries depend only on the file and the limits, so ranks agree on them).
+    `max_sample` (the reference's --max-sample: the first N records of the file) also uses the round-robin
+    form because it needs global record numbers."""
     kind = check_compressed_type(path)
     if world > 1 and max_sample is None and kind in ("Uncompress", "Bgzip"):
-        with FastqReader(path, byte_range=shard_byte_range(path, rank, world)) as rd:
+        with FastqReader(path, byte_range=shard_byte_range(path, rank, world), full_header=full_header) as rd:
             yield from rd.chunks(max_reads, max_bases)
         return
     seen = 0
-    with FastqReader(path) as rd:
+    with FastqReader(path, full_header=full_header) as rd:
         for i, c in enumerate(rd.chunks(max_reads, max_bases)):
             if max_sample is not None and seen + c.n > max_sample:
                 c = c.head(max_sample - seen)
@@ -54,13 +64,72 @@ def limit_batches(it, limit: int | None):
         yield x
 
 
-def _predict(args) -> int:
-    import torch
+def _smooth_params(args):
+    from .predict import SmoothParams
 
-    from . import _lib
-    from .model import HUB_NAMES, DeepChopper
-    from .predict import PredictPipeline, write_pt_batch
+    return SmoothParams(window=args.smooth_window, min_interval=args.min_interval_size, approved=args.approved_intervals,
+                        max_process_intervals=args.max_process_intervals, min_read_length_after_chop=args.min_read_length)
 
+
+def _chunk_limits(args, world: int) -> tuple[int, int]:
+    if args.native or args.chop:
+        return args.max_reads, args.max_tokens  # zero-padding batches bounded by a token budget (config 4)
+    return args.batch_size // world, 1 << 30    # reference batches: per-device reads per step, left-padded
+
+
+def _launch_workers(args, argv: list[str]) -> int:
+    """Parent of a self-launched multi-GPU run: never touches the GPU."""
+    from . import chop as chop_mod
+    from . import launcher
+
+    world = args.gpus
+    path = str(args.data_path)
+    share = os.environ.get("DC_SHARE_GPU") == "1"
+    kind = check_compressed_type(path)
+    feeder = None
+    child = launcher.worker_python() + ["-m", "deepchopper_amd.cli"] + argv
+    part_base = None
+    if args.chop:
+        part_base = chop_mod._temp_name(path, args.chop_output, tag="")
+    per_rank_fds = None
+    if kind == "Gzip" or args.max_sample is not None:
+        max_reads, max_bases = _chunk_limits(args, world)
+        feeder = launcher.ChunkFeeder(path, world, max_reads, max_bases, full_header=bool(args.chop), max_sample=args.max_sample)
+        per_rank_fds = [(fd,) for fd in feeder.read_fds]
+    procs = []
+    port = launcher.free_port()
+    import subprocess
+
+    for r in range(world):
+        env = launcher.rank_env(r, world, port, share)
+        cmd = list(child)
+        if feeder is not None:
+            cmd += ["--chunk-fd", str(feeder.read_fds[r])]
+        if part_base:
+            cmd += ["--part-path", f"{part_base}.rank{r}"]
+        procs.append(subprocess.Popen(cmd, env=env, pass_fds=per_rank_fds[r] if per_rank_fds else (), stdout=subprocess.PIPE, text=True))
+    if feeder is not None:
+        feeder.start()
+    outs = launcher.wait_ranks(procs)
+    if feeder is not None:
+        feeder.join()
+    reports = [launcher.last_json_line(o) for o in outs]
+    n_reads = sum(r["reads"] for r in reports)
+    if n_reads == 0:
+        raise ValueError(f"No valid records found in {path}")
+    summary = {"gpus": world, "reads": n_reads, "batches": sum(r["batches"] for r in reports),
+               "per_rank_reads": [r["reads"] for r in reports]}
+    if args.chop:
+        n_out = sum(r["records"] for r in reports)
+        final = chop_mod._final_name(path, args.chop_output, n_reads, n_out)
+        chop_mod.merge_bgzf_parts([f"{part_base}.rank{r}" for r in range(world)], final)
+        summary.update({"records": n_out, "output": final})
+        print(final)
+    logging.info("%s", json.dumps(summary))
+    return 0
+
+
+def _predict(args, argv: list[str]) -> int:
     data_path = Path(args.data_path)
     if not data_path.exists():
         print(f"Error: Data path '{data_path}' does not exist.", file=sys.stderr)
@@ -68,57 +137,92 @@ def _predict(args) -> int:
     if args.gpus < 1:
         print("Error: deepchopper_amd runs only on the GPU (use --gpus 1..8); there is no CPU fallback.", file=sys.stderr)
         return 1
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.batch_size % max(args.gpus, 1) != 0:  # only_fq.py:198-201
+        raise RuntimeError(f"Batch size ({args.batch_size}) is not divisible by the number of devices ({args.gpus}).")
+    if args.gpus > 1 and world == 1:
+        return _launch_workers(args, argv)  # before anything touches the GPU
+
+    import torch
+
+    from . import _lib
+    from .model import HUB_NAMES, DeepChopper
+    from .predict import PredictPipeline, write_pt_batch
+
     _lib.require_gpu()
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("Error: launch multi-GPU predict with `python -m torch.distributed.run --nproc-per-node N -m "
-              "deepchopper_amd.cli predict ...` (one process per GPU)", file=sys.stderr)
-        return 1
-    if args.batch_size % world != 0:  # only_fq.py:198-201
-        raise RuntimeError(f"Batch size ({args.batch_size}) is not divisible by the number of devices ({world}).")
     torch.cuda.set_device(local_rank)
     model_name = HUB_NAMES.get(args.model.lower(), args.model)
     model = DeepChopper.from_pretrained(model_name)
-    pipe = PredictPipeline(model)
+    pipe = PredictPipeline(model, smooth=_smooth_params(args))
     out_dir = Path(args.output or "predictions")
-    per_dev = args.batch_size // world
-    os.makedirs(out_dir / "0", exist_ok=True)
-    if args.native:
-        # zero-padding batches bounded by a token budget (mixed-length reads, BASELINE config 4)
-        chunks = rank_chunks(str(data_path), rank, world, args.max_reads, args.max_tokens, args.max_sample)
+    max_reads, max_bases = _chunk_limits(args, world)
+    if args.chunk_fd is not None:
+        from .launcher import PipeChunks
+
+        chunks = iter(PipeChunks(args.chunk_fd))  # the parent is this node's single reader / inflater
     else:
-        # reference batches: `per_dev` reads per step on each rank, left-padded to the longest
-        chunks = rank_chunks(str(data_path), rank, world, per_dev, 1 << 30, args.max_sample)
-    n_batches = n_reads = 0
-    if args.native:
-        with open(out_dir / "0" / f"{rank}.intervals.tsv", "w") as tsv:
-            for res in pipe.predict_stream(limit_batches(chunks, args.limit_batches)):
-                iv, niv, lens = res["intervals"], res["n_intervals"], res["lengths"]
-                tsv.write("".join(
-                    f"{name}\t{int(lens[r])}\t" + ",".join(f"{s}:{e}" for s, e in iv[r, : int(niv[r])].tolist()) + "\n"
-                    for r, name in enumerate(res["names"])))
+        chunks = rank_chunks(str(data_path), rank, world, max_reads, max_bases, args.max_sample, full_header=bool(args.chop))
+    chunks = limit_batches(chunks, args.limit_batches)
+    n_batches = n_reads = n_records = 0
+    if args.chop:
+        from .chop import predict_chop
+
+        def count(res):
+            nonlocal n_batches
+            n_batches += 1
+
+        if args.part_path:  # worker of a multi-GPU run: the parent concatenates the parts and names the result
+            _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
+                                                 args.ocq, chunks=chunks, part_path=args.part_path)
+        else:
+            final, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
+                                                     args.ocq, chunks=chunks)
+            print(final)
+    else:
+        os.makedirs(out_dir / "0", exist_ok=True)
+        tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w") if args.native else None
+        try:
+            # reference mode (-b): left-padded batches whose pad tokens run through the model, int64
+            # ids for the .pt wire format; --native: every read at its own length
+            for res in pipe.predict_stream(chunks, reference_padding=not args.native, ids_i64=not args.no_pt,
+                                           want_labels=not args.no_pt):
+                if tsv is not None:
+                    iv, niv, lens = res["intervals"], res["n_intervals"], res["lengths"]
+                    tsv.write("".join(
+                        f"{name}\t{int(lens[r])}\t" + ",".join(f"{s}:{e}" for s, e in iv[r, : int(niv[r])].tolist()) + "\n"
+                        for r, name in enumerate(res["names"])))
                 if not args.no_pt:
                     write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res["device"], res["names"])
                 n_batches += 1
                 n_reads += len(res["names"])
-    else:
-        for chunk in limit_batches(chunks, args.limit_batches):
-            recs = list(chunk.records())
-            ids = [r[0] for r in recs]
-            _, res = pipe.predict_reads(ids, [r[1] for r in recs], [r[2] for r in recs], reference_padding=True)
-            if not args.no_pt:
-                write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res, ids)
-            n_batches += 1
-            n_reads += len(ids)
+        finally:
+            if tsv is not None:
+                tsv.close()
     if n_reads == 0 and world == 1:
         raise ValueError(f"No valid records found in {data_path}")
     logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
+    if os.environ.get("DC_SELF_LAUNCHED") == "1":
+        print(json.dumps({"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records}), flush=True)
     return 0
 
 
+def _add_chop_options(p, prefix_output: bool) -> None:
+    p.add_argument("--smooth-window", type=int, default=21)
+    p.add_argument("--min-interval-size", type=int, default=13)
+    p.add_argument("--approved-intervals", type=int, default=20)
+    p.add_argument("--max-process-intervals", type=int, default=4)
+    p.add_argument("--min-read-length", type=int, default=20)
+    p.add_argument("--chop-type", default="all", choices=["terminal", "internal", "all"])
+    p.add_argument("--ocq", action="store_true", help="output the chopped (adapter) segments only (src/bin/predict.rs:60-62)")
+    p.add_argument("--threads", "-t", type=int, default=2, help="BGZF compression workers for the output (smoothing itself runs on the GPU)")
+    if prefix_output:
+        p.add_argument("--output", "-o", default=None, help="Output prefix")
+
+
 def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser(prog="deepchopper", description="DeepChopper (MI355X-native predict path)")
     sub = ap.add_subparsers(dest="cmd", required=True)
     p = sub.add_parser("predict", help="DeepChopper: predict the given dataset")
@@ -132,23 +236,21 @@ def main(argv=None) -> int:
     p.add_argument("--max-sample", type=int, default=None, help="Maximum number of samples to process")
     p.add_argument("--verbose", "-v", action="store_true", help="Enable verbose output")
     p.add_argument("--native", action="store_true", help="zero-padding batches + per-read intervals TSV")
-    p.add_argument("--max-tokens", type=int, default=2_000_000, help="token budget per --native batch")
+    p.add_argument("--max-tokens", type=int, default=2_000_000, help="token budget per --native / --chop batch")
     p.add_argument("--no-pt", action="store_true", help="skip the 28 B/token .pt wire format (use with --native: "
                    "labels / intervals only)")
-    p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native batch (-b applies to reference batches)")
+    p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native / --chop batch (-b applies to reference batches)")
+    p.add_argument("--chop", action="store_true", help="fused predict -> chop: write the chopped reads as BGZF FASTQ, no .pt files")
+    p.add_argument("--chop-output", default=None, help="output prefix of --chop (default: the FASTQ's stem, as deepchopper chop)")
+    _add_chop_options(p, prefix_output=False)
+    p.add_argument("--chunk-fd", type=int, default=None, help=argparse.SUPPRESS)   # worker: chunks come from the parent
+    p.add_argument("--part-path", default=None, help=argparse.SUPPRESS)            # worker: per-rank BGZF part
     c = sub.add_parser("chop", help="DeepChopper: chop the given predictions!")
     c.add_argument("predicts", nargs="+", help="Paths to prediction folders ({out}/0)")
     c.add_argument("fq", help="Path to FASTQ file")
-    c.add_argument("--smooth-window", type=int, default=21)
-    c.add_argument("--min-interval-size", type=int, default=13)
-    c.add_argument("--approved-intervals", type=int, default=20)
-    c.add_argument("--max-process-intervals", type=int, default=4)
-    c.add_argument("--min-read-length", type=int, default=20)
-    c.add_argument("--chop-type", default="all", choices=["terminal", "internal", "all"])
-    c.add_argument("--output", "-o", default=None, help="Output prefix")
+    _add_chop_options(c, prefix_output=True)
     c.add_argument("--max-batch", type=int, default=None)
     c.add_argument("--chunk-size", type=int, default=10000)
-    c.add_argument("--threads", "-t", type=int, default=2, help="BGZF compression workers for the output (smoothing itself runs on the GPU)")
     c.add_argument("--verbose", "-v", action="store_true")
     args = ap.parse_args(argv)
     if args.verbose:
@@ -156,16 +258,13 @@ def main(argv=None) -> int:
     if args.cmd == "chop":
         from . import _lib
         from .chop import chop
-        from .predict import SmoothParams
 
         _lib.require_gpu()
-        sp = SmoothParams(window=args.smooth_window, min_interval=args.min_interval_size,
-                          approved=args.approved_intervals, max_process_intervals=args.max_process_intervals,
-                          min_read_length_after_chop=args.min_read_length)
-        path = chop(args.predicts, args.fq, sp, args.chop_type, args.output, args.chunk_size, args.max_batch, args.threads)
+        path = chop(args.predicts, args.fq, _smooth_params(args), args.chop_type, args.output, args.chunk_size, args.max_batch,
+                    args.threads, args.ocq)
         print(path)
         return 0
-    return _predict(args)
+    return _predict(args, argv)
 
 
 if __name__ == "__main__":

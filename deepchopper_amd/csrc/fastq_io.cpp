@@ -365,8 +365,12 @@ int64_t dc_fq_records_read(const dc_fq_reader* r) { return r ? r->n_records : 0;
 int64_t dc_fq_bytes_consumed(const dc_fq_reader* r) { return r ? r->src.consumed.load() : 0; }
 void dc_fq_close(dc_fq_reader* r) { delete r; }
 
-int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
-                     int64_t* offsets, char* names, int64_t cap_names, int64_t* name_offsets, int64_t* n_reads) {
+// name_len == nullptr: `names` receives the name part of every definition line (up to the first blank or
+// tab).  Otherwise `names` receives the whole definition line after '@' and name_len[r] the length of its
+// name part.
+static int read_chunk_impl(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
+                           int64_t* offsets, char* names, int64_t cap_names, int64_t* name_offsets, int32_t* name_len,
+                           int64_t* n_reads) {
   if (!r || !seq || !qual || !offsets || !names || !name_offsets || !n_reads || max_reads < 0 || cap_bases < 0 || cap_names < 0)
     return fail(DC_FQ_ERR_ARG, "invalid argument");
   int rc = 0;
@@ -409,18 +413,21 @@ int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* 
     size_t nm0 = s0 + 1, nm1 = nm0;
     while (nm1 < h_end && d[nm1] != ' ' && d[nm1] != '\t') ++nm1;
     int64_t ls = (int64_t)(sq_end - s1), lq = (int64_t)(q_end - s3), ln = (int64_t)(nm1 - nm0);
-    if (ln == 0 || ls == 0 || lq == 0)
+    const int64_t lname = ln;
+    if (name_len) ln = (int64_t)(h_end - nm0);  // whole definition line
+    if (lname == 0 || ls == 0 || lq == 0)
       return fail(DC_FQ_ERR_INCOMPLETE, "Incomplete FASTQ record at position %lld in %s", (long long)recno, r->path.c_str());
     if (ls != lq)
-      return fail(DC_FQ_ERR_LENGTH, "Sequence/quality length mismatch in record '%.*s': seq=%lld, qual=%lld", (int)ln,
+      return fail(DC_FQ_ERR_LENGTH, "Sequence/quality length mismatch in record '%.*s': seq=%lld, qual=%lld", (int)lname,
                   (const char*)d + nm0, (long long)ls, (long long)lq);
     if (nb + ls > cap_bases || nn + ln > cap_names) {
-      if (n == 0) return fail(DC_FQ_ERR_ARG, "record '%.*s' (%lld bases) does not fit the chunk buffers", (int)ln, (const char*)d + nm0, (long long)ls);
+      if (n == 0) return fail(DC_FQ_ERR_ARG, "record '%.*s' (%lld bases) does not fit the chunk buffers", (int)lname, (const char*)d + nm0, (long long)ls);
       break;  // deliver what we have; this record starts the next chunk
     }
     memcpy(seq + nb, d + s1, (size_t)ls);
     memcpy(qual + nb, d + s3, (size_t)ls);
     memcpy(names + nn, d + nm0, (size_t)ln);
+    if (name_len) name_len[n] = (int32_t)lname;
     nb += ls;
     nn += ln;
     ++n;
@@ -431,6 +438,18 @@ int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* 
   }
   *n_reads = n;
   return 0;
+}
+
+int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
+                     int64_t* offsets, char* names, int64_t cap_names, int64_t* name_offsets, int64_t* n_reads) {
+  return read_chunk_impl(r, max_reads, seq, qual, cap_bases, offsets, names, cap_names, name_offsets, nullptr, n_reads);
+}
+
+int dc_fq_read_chunk_full(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
+                          int64_t* offsets, char* headers, int64_t cap_headers, int64_t* header_offsets,
+                          int32_t* name_len, int64_t* n_reads) {
+  if (!name_len) return fail(DC_FQ_ERR_ARG, "invalid argument");
+  return read_chunk_impl(r, max_reads, seq, qual, cap_bases, offsets, headers, cap_headers, header_offsets, name_len, n_reads);
 }
 
 }  // extern "C"
@@ -621,3 +640,115 @@ int dc_bgzf_close(dc_bgzf_writer* w) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Chop stage of the fused predict -> chop flow: gating + record splitting + FASTQ text, straight from the
+// reader's packed chunk and the smoothing kernel's per-read intervals into the BGZF writer.
+//   process_chunk                              src/bin/predict.rs:130-192
+//   split_noodle_records_by_remove_intervals   src/output/split.rs:171-226 (+ helper :60-136)
+//   split_noodle_records_by_intervals (--ocq)  src/output/split.rs:138-169
+//   Predict.seq = id_list2seq(tokens)          src/smooth/predict.rs:264-317, src/smooth/utils.rs:6-25
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// Letter the reference's `Predict.seq` holds for a raw FASTQ base: pyfastx upper-cases, needletail
+// normalises (acgtn -> upper, U -> T, everything else -> N or '-'), the character tokenizer maps
+// anything outside ACGTN to [UNK], and id_list2seq turns every id outside 7..11 into 'N'.
+struct LetterLut {
+  uint8_t t[256];
+  LetterLut() {
+    memset(t, 'N', sizeof t);
+    t['A'] = t['a'] = 'A';
+    t['C'] = t['c'] = 'C';
+    t['G'] = t['g'] = 'G';
+    t['T'] = t['t'] = t['U'] = t['u'] = 'T';
+  }
+};
+const LetterLut kLetters;
+
+}  // namespace
+
+extern "C" int dc_chop_write_chunk(dc_bgzf_writer* w, const dc_chop_params* p, int64_t n, const char* headers,
+                                   const int64_t* header_offsets, const int32_t* name_len, const uint8_t* seq,
+                                   const uint8_t* qual, const int64_t* offsets, const int32_t* pred_len,
+                                   const int32_t* n_intervals, const int32_t* intervals, int32_t max_intervals,
+                                   const int32_t* n_keep, const int32_t* keep, int32_t max_keep,
+                                   int32_t* records_per_read, int64_t* n_records_out) {
+  if (!w || !p || n < 0 || (n && (!headers || !header_offsets || !seq || !qual || !offsets || !pred_len || !n_intervals)))
+    return fail(DC_FQ_ERR_ARG, "invalid argument");
+  if (p->chop_type < 0 || p->chop_type > 2) return fail(DC_FQ_ERR_ARG, "Invalid chop type");
+  if (p->output_chopped_seqs ? !intervals : (!keep || !n_keep)) return fail(DC_FQ_ERR_ARG, "missing interval arrays");
+  std::vector<uint8_t> rec, letters;
+  int64_t total = 0;
+  char tag[64];
+  auto emit = [&](const char* id, size_t id_len, const char* suffix, size_t suffix_len, const uint8_t* s,
+                  const uint8_t* q, size_t len) -> int {
+    rec.clear();
+    rec.push_back('@');
+    rec.insert(rec.end(), id, id + id_len);
+    rec.insert(rec.end(), suffix, suffix + suffix_len);
+    rec.push_back('\n');
+    rec.insert(rec.end(), s, s + len);
+    rec.push_back('\n');
+    rec.push_back('+');
+    rec.push_back('\n');
+    rec.insert(rec.end(), q, q + len);
+    rec.push_back('\n');
+    ++total;
+    return w->put(rec.data(), rec.size());
+  };
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t a = offsets[i], b = offsets[i + 1], ha = header_offsets[i], hb = header_offsets[i + 1];
+    if (b < a || hb < ha) return fail(DC_FQ_ERR_ARG, "offsets not monotonic at record %lld", (long long)i);
+    const int64_t L = b - a, before = total;
+    const int64_t idl = name_len ? name_len[i] : hb - ha;
+    if (idl < 0 || idl > hb - ha) return fail(DC_FQ_ERR_ARG, "bad name length at record %lld", (long long)i);
+    const char* id = headers + ha;
+    const int32_t pl = pred_len[i], niv = n_intervals[i];
+    int rc = 0;
+    // predict.rs:146-164: short reads, no / too many intervals, truncated predictions -> the record as read
+    if (pl < p->min_read_len || niv == 0 || niv > p->max_process_intervals || (int64_t)pl != L) {
+      if ((rc = emit(id, (size_t)(hb - ha), "", 0, seq + a, qual + a, (size_t)L))) return rc;
+      if (records_per_read) records_per_read[i] = 1;
+      continue;
+    }
+    if (niv < 0 || niv > max_intervals) return fail(DC_FQ_ERR_ARG, "interval count out of range at record %lld", (long long)i);
+    letters.resize((size_t)L);
+    for (int64_t k = 0; k < L; ++k) letters[(size_t)k] = kLetters.t[seq[a + k]];
+    if (p->output_chopped_seqs) {  // --ocq: the chopped (adapter) segments themselves
+      const int32_t* iv = intervals + (size_t)i * max_intervals * 2;
+      for (int32_t k = 0; k < niv; ++k) {
+        const int64_t s = iv[2 * k], e = iv[2 * k + 1];
+        if (s < 0 || e < s || e > L) return fail(DC_FQ_ERR_ARG, "The interval is invalid: %lld..%lld", (long long)s, (long long)e);
+        int tl = snprintf(tag, sizeof tag, "|%lld:%lld", (long long)s, (long long)e);
+        if ((rc = emit(id, (size_t)idl, tag, (size_t)tl, letters.data() + s, qual + a + s, (size_t)(e - s)))) return rc;
+      }
+    } else {
+      const int32_t nk = n_keep[i];
+      if (nk < 0 || nk > max_keep) return fail(DC_FQ_ERR_ARG, "segment count out of range at record %lld", (long long)i);
+      const int32_t* kp = keep + (size_t)i * max_keep * 2;
+      const bool terminal = nk == 1;  // record count BEFORE the length filter (split.rs:182-188)
+      int64_t first_len = -1;
+      for (int32_t k = 0; k < nk && first_len < 0; ++k) {
+        const int64_t s = kp[2 * k], e = kp[2 * k + 1];
+        if (s < 0 || e < s || e > L) return fail(DC_FQ_ERR_ARG, "The interval is invalid: %lld..%lld", (long long)s, (long long)e);
+        if (e - s >= p->min_read_length_after_chop) first_len = e - s;
+      }
+      if ((p->chop_type == 0 && !terminal) || (p->chop_type == 1 && terminal) || first_len == L) {
+        if ((rc = emit(id, (size_t)idl, "", 0, letters.data(), qual + a, (size_t)L))) return rc;
+      } else {
+        for (int32_t k = 0; k < nk; ++k) {
+          const int64_t s = kp[2 * k], e = kp[2 * k + 1];
+          if (s < 0 || e < s || e > L) return fail(DC_FQ_ERR_ARG, "The interval is invalid: %lld..%lld", (long long)s, (long long)e);
+          if (e - s < p->min_read_length_after_chop) continue;
+          int tl = snprintf(tag, sizeof tag, "|%lld:%lld%s", (long long)s, (long long)e,
+                            p->id_annotation ? (terminal ? "|T" : "|I") : "");
+          if ((rc = emit(id, (size_t)idl, tag, (size_t)tl, letters.data() + s, qual + a + s, (size_t)(e - s)))) return rc;
+        }
+      }
+    }
+    if (records_per_read) records_per_read[i] = (int32_t)(total - before);
+  }
+  if (n_records_out) *n_records_out = total;
+  return 0;
+}

@@ -112,6 +112,9 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);
+int launch_load_hidden(hipStream_t st, const float* hidden, const float* quals, int D, const int32_t* blk_read,
+                       const int32_t* toff, const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x,
+                       float* qpad);
 int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd);
 int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
                        const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,

@@ -57,6 +57,7 @@ struct dc_model {
   int mlp_chain = 1;                 // fused MLP kernel also runs the GEMM that consumes LayerNorm(its output)
   float is_l1 = 1.f, is_l2 = 1.f;
   int* d_overflow = nullptr;  // fp16x3 range guard (device counter)
+  int* ovf_target = nullptr;  // caller-owned counter that replaces it (dc_model_set_overflow_target)
   float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
   int mlp_fusion = 1;  // fp16x3: fc1 -> GELU -> fc2 in one kernel (dc_model_set_mlp_fusion)
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
@@ -362,7 +363,7 @@ int run_gemm(dc_model* m, hipStream_t st, const char* name, const WRef& w, const
   g.Wp = m->gemm_mode == 1 ? w.Wp : (m->gemm_mode == 2 ? w.Wq : nullptr);
   g.split_mode = m->gemm_mode == 2 ? 1 : 0;
   g.w_inv_scale = m->gemm_mode == 2 ? w.inv_scale : 1.0f;
-  g.overflow = m->d_overflow;
+  g.overflow = m->ovf_target ? m->ovf_target : m->d_overflow;
   g.X = X;
   g.C = C;
   g.bias = bias;
@@ -486,6 +487,50 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   return DC_OK;
 }
 
+// Final LayerNorm (folded into linear1) + token-classification head on the residual stream in m->x.
+// head_sums: mean / rstd hold the per-token sum / sum of squares left by the last fc2 epilogue;
+// head1_ready: linear1 already ran inside the last block's fused MLP kernel (its output is in m->hmid).
+int run_head(dc_model* m, hipStream_t st, bool head_sums, bool head1_ready, float* d_logits) {
+  const auto& c = m->cfg;
+  const int D = c.d_model, H = c.head_hidden;
+  float* x = (float*)m->x.p;
+  float* hm = (float*)m->hmid.p;
+  float* ob = (float*)m->obuf.p;
+  float* mean = (float*)m->mean.p;
+  float* rstd = (float*)m->rstd.p;
+  float* qpad = (float*)m->qpad.p;
+  const int64_t Tp = m->Tp;
+  int rc;
+  if (!head_sums && !head1_ready) {
+    ProfScope ps(m, st, "ln_stats");
+    if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
+  }
+  if (!head1_ready &&
+      (rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
+                     head_sums)))
+    return rc;
+  static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
+  if (m->gemm_mode >= 1 && !no_head_fuse) {
+    // linear2 + residual + ReLU + linear3 in one kernel: the 1024-wide activation never reaches HBM
+    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
+                       H)))
+      return rc;
+    ProfScope ps(m, st, "head_out");
+    if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / gemm6_channel_block(), m->b3, Tp, m->d_blk_read, m->d_toff,
+                                 m->d_src_base, m->d_ntok, d_logits)))
+      return rc;
+  } else {
+    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
+                       H, H)))
+      return rc;
+    ProfScope ps(m, st, "head_out");
+    if ((rc = launch_head_out(st, ob, m->W3, m->b3, H, c.num_class, Tp, m->d_blk_read, m->d_toff, m->d_src_base,
+                              m->d_ntok, d_logits)))
+      return rc;
+  }
+  return DC_OK;
+}
+
 int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, const float* d_quals, int n_reads,
                  int64_t row_stride, const int32_t* h_first, const int32_t* h_ntok, float* d_logits) {
   const auto& c = m->cfg;
@@ -499,7 +544,6 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   float* u = (float*)m->u.p;
   float* y = (float*)m->y.p;
   float* hm = (float*)m->hmid.p;
-  float* ob = (float*)m->obuf.p;
   float* mean = (float*)m->mean.p;
   float* rstd = (float*)m->rstd.p;
   float* qpad = (float*)m->qpad.p;
@@ -571,7 +615,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.kfp_f16 = L.kfq;
       a.ch_inv_scale = L.kinv;
       a.split_mode = m->gemm_mode == 2 ? 1 : 0;
-      a.overflow = m->d_overflow;
+      a.overflow = m->ovf_target ? m->ovf_target : m->d_overflow;
       if (li == 0 && l0_gather) {
         a.tok = tokp;
         a.tab = m->u_table0;
@@ -605,7 +649,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       g.w_inv_scale2 = L.is_fc2;
       g.bias = L.b_fc1;
       g.bias2 = L.b_fc2;
-      g.overflow = m->d_overflow;
+      g.overflow = m->ovf_target ? m->ovf_target : m->d_overflow;
       g.X = x;
       g.R = x;
       g.C = x;
@@ -655,35 +699,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         return rc;
     }
   }
-  const bool head_sums = fused_stats && l0_table;
-  if (!head_sums && !head1_ready) {
-    ProfScope ps(m, st, "ln_stats");
-    if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
-  }
-  if (!head1_ready &&
-      (rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
-                     head_sums)))
-    return rc;
-  static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
-  if (m->gemm_mode >= 1 && !no_head_fuse) {
-    // linear2 + residual + ReLU + linear3 in one kernel: the 1024-wide activation never reaches HBM
-    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
-                       H)))
-      return rc;
-    ProfScope ps(m, st, "head_out");
-    if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / gemm6_channel_block(), m->b3, Tp, m->d_blk_read, m->d_toff,
-                                 m->d_src_base, m->d_ntok, d_logits)))
-      return rc;
-  } else {
-    if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
-                       H, H)))
-      return rc;
-    ProfScope ps(m, st, "head_out");
-    if ((rc = launch_head_out(st, ob, m->W3, m->b3, H, c.num_class, Tp, m->d_blk_read, m->d_toff, m->d_src_base,
-                              m->d_ntok, d_logits)))
-      return rc;
-  }
-  return DC_OK;
+  return run_head(m, st, fused_stats && l0_table, head1_ready, d_logits);
 }
 
 }  // namespace
@@ -865,6 +881,21 @@ extern "C" int dc_forward_ragged(dc_model* m, void* stream, const void* d_input_
                       h_n_tokens, d_logits);
 }
 
+extern "C" int dc_head_forward(dc_model* m, void* stream, const float* d_hidden, const float* d_input_quals,
+                               int32_t batch, int32_t seq_len, float* d_logits) {
+  DC_REQUIRE(m && d_hidden && d_input_quals && d_logits, "null pointer");
+  DC_REQUIRE(batch >= 1 && seq_len >= 1, "batch and seq_len must be positive");
+  hipStream_t st = as_stream(stream);
+  std::vector<int32_t> first(batch, 0), ntok(batch, seq_len);
+  int rc;
+  if ((rc = setup_geometry(m, st, batch, seq_len, first.data(), ntok.data()))) return rc;
+  if ((rc = ensure_workspace(m, m->Tp))) return rc;
+  if ((rc = launch_load_hidden(st, d_hidden, d_input_quals, m->cfg.d_model, m->d_blk_read, m->d_toff, m->d_src_base,
+                               m->d_ntok, m->Tp, (float*)m->x.p, (float*)m->qpad.p)))
+    return rc;
+  return run_head(m, st, /*head_sums=*/false, /*head1_ready=*/false, d_logits);
+}
+
 extern "C" int64_t dc_model_device_bytes(const dc_model* m) {
   if (!m) return 0;
   int64_t b = m->weight_bytes;
@@ -910,6 +941,18 @@ extern "C" int dc_model_overflow(dc_model* m, void* stream, int32_t* count) {
   DC_HIP_CHECK(hipStreamSynchronize(st));
   if (v) DC_HIP_CHECK(hipMemsetAsync(m->d_overflow, 0, sizeof(int), st));
   *count = v;
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_overflow_target(dc_model* m, int32_t* d_counter) {
+  DC_REQUIRE(m, "null pointer");
+  m->ovf_target = d_counter;
+  return DC_OK;
+}
+
+extern "C" int dc_model_get_gemm_mode(const dc_model* m, int32_t* mode) {
+  DC_REQUIRE(m && mode, "null pointer");
+  *mode = m->gemm_mode;
   return DC_OK;
 }
 

@@ -1608,6 +1608,36 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
   for (int c = 0; c < D; ++c) x[(int64_t)c * Tp + t] = id >= 0 ? s_emb[id * D + c] : 0.f;
 }
 
+// Diagnostic (dc_head_forward): a caller-supplied residual stream hidden[read][token][D] (token-major, the
+// layout of the reference's `hidden_states`) scattered into the packed channel-major layout.
+__global__ __launch_bounds__(256) void load_hidden_kernel(const float* __restrict__ hidden,
+                                                          const float* __restrict__ quals, int D,
+                                                          const int32_t* __restrict__ blk_read,
+                                                          const int32_t* __restrict__ toff,
+                                                          const int64_t* __restrict__ src_base,
+                                                          const int32_t* __restrict__ ntok, int64_t Tp,
+                                                          float* __restrict__ x, float* __restrict__ qpad) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= Tp) return;
+  const int r = blk_read[t >> 5];
+  int64_t s = -1;
+  if (r >= 0) {
+    const int l = (int)(t - toff[r]);
+    if (l < ntok[r]) s = src_base[r] + l;
+  }
+  qpad[t] = s >= 0 ? quals[s] : 0.f;
+  for (int c = 0; c < D; ++c) x[(int64_t)c * Tp + t] = s >= 0 ? hidden[s * D + c] : 0.f;
+}
+
+int launch_load_hidden(hipStream_t st, const float* hidden, const float* quals, int D, const int32_t* blk_read,
+                       const int32_t* toff, const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x,
+                       float* qpad) {
+  load_hidden_kernel<<<dim3((unsigned)((Tp + 255) / 256)), dim3(256), 0, st>>>(hidden, quals, D, blk_read, toff,
+                                                                                 src_base, ntok, Tp, x, qpad);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
 // =====================================================================================
 // LayerNorm statistics per token (mean, 1/sqrt(var + eps)), two-pass in registers
 // =====================================================================================

@@ -26,13 +26,17 @@ def check_compressed_type(path: str) -> str:
 
 
 class FastqChunk:
-    """n reads as packed buffers (views into the reader's reusable arrays: copy to keep)."""
+    """n reads as packed buffers (views into the reader's reusable arrays: copy to keep).
 
-    __slots__ = ("n", "seq", "qual", "offsets", "_names", "_name_offsets")
+    `_names` / `_name_offsets` hold one string per read: its name (definition line up to the first blank),
+    or -- from a reader opened with `full_header=True` -- the whole definition line, with `_name_len[r]`
+    giving the length of the name part."""
 
-    def __init__(self, n, seq, qual, offsets, names, name_offsets):
+    __slots__ = ("n", "seq", "qual", "offsets", "_names", "_name_offsets", "_name_len")
+
+    def __init__(self, n, seq, qual, offsets, names, name_offsets, name_len=None):
         self.n, self.seq, self.qual, self.offsets = n, seq, qual, offsets
-        self._names, self._name_offsets = names, name_offsets
+        self._names, self._name_offsets, self._name_len = names, name_offsets, name_len
 
     @property
     def lengths(self) -> np.ndarray:
@@ -42,17 +46,24 @@ class FastqChunk:
         """The first k reads of the chunk."""
         k = max(0, min(int(k), self.n))
         nb, nn = int(self.offsets[k]), int(self._name_offsets[k])
-        return FastqChunk(k, self.seq[:nb], self.qual[:nb], self.offsets[: k + 1], self._names[:nn], self._name_offsets[: k + 1])
+        return FastqChunk(k, self.seq[:nb], self.qual[:nb], self.offsets[: k + 1], self._names[:nn], self._name_offsets[: k + 1],
+                          None if self._name_len is None else self._name_len[:k])
 
     def names(self) -> list[str]:
-        raw = self._names.tobytes()
-        o = self._name_offsets
-        return [raw[o[i]: o[i + 1]].decode("latin1") for i in range(self.n)]
+        return decode_names(self._names, self._name_offsets, self._name_len, self.n)
 
     def records(self) -> Iterator[tuple[str, bytes, bytes]]:
         s, q, o = self.seq.tobytes(), self.qual.tobytes(), self.offsets
         for i, name in enumerate(self.names()):
             yield name, s[o[i]: o[i + 1]], q[o[i]: o[i + 1]]
+
+
+def decode_names(names: np.ndarray, name_offsets: np.ndarray, name_len: np.ndarray | None, n: int) -> list[str]:
+    raw = names.tobytes()
+    o = name_offsets
+    if name_len is None:
+        return [raw[o[i]: o[i + 1]].decode("latin1") for i in range(n)]
+    return [raw[o[i]: o[i] + int(name_len[i])].decode("latin1") for i in range(n)]
 
 
 class FastqReader:
@@ -61,8 +72,10 @@ class FastqReader:
     `byte_range=(b0, b1)` opens a shard of an uncompressed file: the records whose '@' line starts in
     [b0, b1) -- ranks tile the file with `shard_byte_range` and never parse each other's reads."""
 
-    def __init__(self, path: str, *, byte_range: tuple[int, int] | None = None, readahead: int = 4):
+    def __init__(self, path: str, *, byte_range: tuple[int, int] | None = None, readahead: int = 4,
+                 full_header: bool = False):
         self.path = str(path)
+        self.full_header = bool(full_header)  # chunks carry whole definition lines (the chop stage needs them)
         self._h = C.c_void_p()
         L = _iolib.lib()
         if byte_range is None:
@@ -78,7 +91,7 @@ class FastqReader:
     def _buffers(self, max_reads: int, cap_bases: int, cap_names: int):
         if self._cap != (max_reads, cap_bases, cap_names):
             self._bufs = (np.empty(cap_bases, np.uint8), np.empty(cap_bases, np.uint8), np.empty(max_reads + 1, np.int64),
-                          np.empty(cap_names, np.uint8), np.empty(max_reads + 1, np.int64))
+                          np.empty(cap_names, np.uint8), np.empty(max_reads + 1, np.int64), np.empty(max_reads, np.int32))
             self._cap = (max_reads, cap_bases, cap_names)
         return self._bufs
 
@@ -87,17 +100,23 @@ class FastqReader:
         reused by the next call."""
         if not self._h:
             raise ValueError("reader is closed")
-        cap_names = cap_names or max(256 * max_reads, 1 << 16)
-        seq, qual, offs, names, noffs = self._buffers(max_reads, cap_bases, cap_names)
+        cap_names = cap_names or max((1024 if self.full_header else 256) * max_reads, 1 << 16)
+        seq, qual, offs, names, noffs, nlen = self._buffers(max_reads, cap_bases, cap_names)
         n = C.c_int64(0)
-        rc = _iolib.lib().dc_fq_read_chunk(self._h, max_reads, seq.ctypes.data, qual.ctypes.data, cap_bases, offs.ctypes.data,
-                                           names.ctypes.data, cap_names, noffs.ctypes.data, C.byref(n))
+        if self.full_header:
+            rc = _iolib.lib().dc_fq_read_chunk_full(self._h, max_reads, seq.ctypes.data, qual.ctypes.data, cap_bases,
+                                                    offs.ctypes.data, names.ctypes.data, cap_names, noffs.ctypes.data,
+                                                    nlen.ctypes.data, C.byref(n))
+        else:
+            rc = _iolib.lib().dc_fq_read_chunk(self._h, max_reads, seq.ctypes.data, qual.ctypes.data, cap_bases, offs.ctypes.data,
+                                               names.ctypes.data, cap_names, noffs.ctypes.data, C.byref(n))
         _iolib.raise_for(rc)
         k = n.value
         if k == 0:
             return None
         nb = int(offs[k])
-        return FastqChunk(k, seq[:nb], qual[:nb], offs[: k + 1], names[: int(noffs[k])], noffs[: k + 1])
+        return FastqChunk(k, seq[:nb], qual[:nb], offs[: k + 1], names[: int(noffs[k])], noffs[: k + 1],
+                          nlen[:k] if self.full_header else None)
 
     def chunks(self, max_reads: int = 4096, cap_bases: int = 8 << 20) -> Iterator[FastqChunk]:
         while True:
@@ -170,6 +189,25 @@ class BgzfWriter:
         _iolib.raise_for(_iolib.lib().dc_bgzf_write_fastq(
             self._h, chunk.n, chunk._names.ctypes.data, chunk._name_offsets.ctypes.data, chunk.seq.ctypes.data,
             chunk.qual.ctypes.data, chunk.offsets.ctypes.data))
+
+    def chop_write_chunk(self, params: "_iolib.ChopParams", n: int, headers, header_offsets, name_len, seq, qual, offsets,
+                         pred_len, n_intervals, intervals, n_keep, keep, records_per_read=None) -> int:
+        """dc_chop_write_chunk: gate + split + write the records of one chunk; returns the records written.
+        All arguments are C-contiguous numpy arrays (intervals int32[n, max_iv, 2], keep int32[n, max_keep, 2])."""
+        def ptr(a, dt):
+            if a is None:
+                return None
+            assert a.dtype == dt and a.flags.c_contiguous, (a.dtype, dt)
+            return a.ctypes.data
+
+        total = C.c_int64(0)
+        _iolib.raise_for(_iolib.lib().dc_chop_write_chunk(
+            self._h, C.byref(params), n, ptr(headers, np.uint8), ptr(header_offsets, np.int64), ptr(name_len, np.int32),
+            ptr(seq, np.uint8), ptr(qual, np.uint8), ptr(offsets, np.int64), ptr(pred_len, np.int32),
+            ptr(n_intervals, np.int32), ptr(intervals, np.int32), intervals.shape[1] if intervals is not None else 0,
+            ptr(n_keep, np.int32), ptr(keep, np.int32), keep.shape[1] if keep is not None else 0,
+            ptr(records_per_read, np.int32), C.byref(total)))
+        return int(total.value)
 
     def close(self) -> None:
         if self._h:

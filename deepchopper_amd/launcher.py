@@ -1,0 +1,261 @@
+"""One process per GPU, started by the command itself (`deepchopper predict --gpus N`, `bench.py --gpus N`).
+
+The reference launches its own per-device workers through Lightning (`accelerator="gpu", devices=N`,
+deepchopper/cli.py:126-147).  Here the parent process -- which never touches the GPU, so nothing that has
+initialised HIP is ever forked or exec'ed -- starts N fresh interpreters with RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_* in their environment (the variables `torch.distributed.run` would set, so a worker
+cannot tell the two launchers apart), waits for them and merges what they report.  Reads shard with no
+data-path collective, so there is nothing else to coordinate.
+
+Plain gzip cannot be entered mid-stream, and eight ranks each inflating the whole file would spend
+8 x the CPU to go no faster than one zlib stream.  `ChunkFeeder` is the node's single inflater for that
+case: the parent parses the file ONCE with the native reader and deals the packed chunks round-robin to the
+workers over pipes (`PipeChunks` on the other end yields `FastqChunk`s exactly like a local reader).
+"""
+from __future__ import annotations
+
+import json
+import os
+import socket
+import struct
+import subprocess
+import sys
+import threading
+from typing import Iterator
+
+import numpy as np
+
+from .fastq import FastqChunk, FastqReader
+
+_MAGIC = 0x44434651  # "DCFQ"
+_HDR = struct.Struct("<IIqqq")  # magic, has_name_len, n, seq bytes, header bytes
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank: int, world: int, port: int, share_gpu: bool = False) -> dict:
+    """Environment of worker `rank`: what torch.distributed.run would export.  share_gpu: every worker uses
+    device 0 (rehearsing the N > 1 path on a one-GPU box)."""
+    env = dict(os.environ)
+    env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0" if share_gpu else str(rank),
+                "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "DC_SELF_LAUNCHED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def spawn_ranks(argv: list[str], world: int, *, share_gpu: bool = False, extra_env: dict | None = None,
+                pass_fds_per_rank: list[tuple[int, ...]] | None = None, cwd: str | None = None,
+                capture_stdout: bool = True) -> list[subprocess.Popen]:
+    """Start `world` workers running `argv` (rank r gets rank_env(r)).  The caller must not have initialised
+    the GPU.  stdout of every worker is piped back (its last line is the worker's JSON report)."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = rank_env(r, world, port, share_gpu)
+        if extra_env:
+            env.update(extra_env)
+        fds = pass_fds_per_rank[r] if pass_fds_per_rank else ()
+        procs.append(subprocess.Popen(argv, env=env, cwd=cwd, pass_fds=fds,
+                                      stdout=subprocess.PIPE if capture_stdout else None, text=capture_stdout))
+    return procs
+
+
+def wait_ranks(procs: list[subprocess.Popen], timeout: float | None = None) -> list[str]:
+    """Wait for every worker; returns their stdout.  A failing worker terminates the others and raises."""
+    outs = [""] * len(procs)
+    threads = []
+
+    def drain(i, p):
+        outs[i] = p.stdout.read() if p.stdout else ""
+
+    for i, p in enumerate(procs):
+        t = threading.Thread(target=drain, args=(i, p), daemon=True)
+        t.start()
+        threads.append(t)
+    import time
+
+    failed = None
+    deadline = None if timeout is None else time.monotonic() + timeout
+    try:
+        while failed is None and any(p.poll() is None for p in procs):
+            for i, p in enumerate(procs):
+                rc = p.poll()
+                if rc not in (None, 0):
+                    failed = (i, rc)
+                    break
+            if deadline is not None and time.monotonic() > deadline:
+                raise TimeoutError(f"workers still running after {timeout} s")
+            if failed is None:
+                time.sleep(0.05)
+        if failed is None:
+            for i, p in enumerate(procs):
+                if p.returncode != 0:
+                    failed = (i, p.returncode)
+                    break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    for t in threads:
+        t.join(timeout=5)
+    if failed is not None:
+        raise RuntimeError(f"worker rank {failed[0]} exited with status {failed[1]}")
+    return outs
+
+
+def last_json_line(text: str) -> dict:
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            return json.loads(line)
+    raise ValueError("worker printed no JSON report")
+
+
+# ----------------------------------------------------------------------------------------------------
+# chunk transport: parent (single reader / inflater) -> workers
+# ----------------------------------------------------------------------------------------------------
+def write_chunk(fh, c: FastqChunk) -> None:
+    """One frame: header, then offsets int64[n+1], header offsets int64[n+1], name_len int32[n] (optional),
+    seq, qual, headers."""
+    n, nb, nn = c.n, int(c.offsets[c.n]), int(c._name_offsets[c.n])
+    fh.write(_HDR.pack(_MAGIC, 0 if c._name_len is None else 1, n, nb, nn))
+    fh.write(np.ascontiguousarray(c.offsets[: n + 1], np.int64).tobytes())
+    fh.write(np.ascontiguousarray(c._name_offsets[: n + 1], np.int64).tobytes())
+    if c._name_len is not None:
+        fh.write(np.ascontiguousarray(c._name_len[:n], np.int32).tobytes())
+    fh.write(memoryview(np.ascontiguousarray(c.seq[:nb])))
+    fh.write(memoryview(np.ascontiguousarray(c.qual[:nb])))
+    fh.write(memoryview(np.ascontiguousarray(c._names[:nn])))
+
+
+def _read_exact(fh, n: int) -> bytes:
+    buf = bytearray(n)
+    view, got = memoryview(buf), 0
+    while got < n:
+        k = fh.readinto(view[got:])
+        if not k:
+            raise EOFError("chunk stream ended inside a frame")
+        got += k
+    return bytes(buf)
+
+
+def read_chunk(fh) -> FastqChunk | None:
+    head = fh.read(_HDR.size)
+    if not head:
+        return None
+    if len(head) < _HDR.size:
+        head += _read_exact(fh, _HDR.size - len(head))
+    magic, has_len, n, nb, nn = _HDR.unpack(head)
+    if magic != _MAGIC:
+        raise ValueError("bad chunk frame")
+    offs = np.frombuffer(_read_exact(fh, 8 * (n + 1)), np.int64)
+    hoffs = np.frombuffer(_read_exact(fh, 8 * (n + 1)), np.int64)
+    nlen = np.frombuffer(_read_exact(fh, 4 * n), np.int32) if has_len else None
+    seq = np.frombuffer(_read_exact(fh, nb), np.uint8)
+    qual = np.frombuffer(_read_exact(fh, nb), np.uint8)
+    names = np.frombuffer(_read_exact(fh, nn), np.uint8)
+    return FastqChunk(n, seq, qual, offs, names, hoffs, nlen)
+
+
+class PipeChunks:
+    """Worker side: `for chunk in PipeChunks(fd)` yields the chunks the parent dealt to this rank."""
+
+    def __init__(self, fd: int):
+        self._fh = os.fdopen(fd, "rb", buffering=1 << 20)
+
+    def __iter__(self) -> Iterator[FastqChunk]:
+        while True:
+            c = read_chunk(self._fh)
+            if c is None:
+                return
+            yield c
+
+    def close(self):
+        self._fh.close()
+
+
+class ChunkFeeder:
+    """Parent side: parse `path` once and deal its chunks round-robin to `world` pipes.  One writer thread per
+    pipe with a short queue, so a worker that is momentarily busy does not stall the others' supply."""
+
+    def __init__(self, path: str, world: int, max_reads: int, max_bases: int, *, full_header: bool = False,
+                 max_sample: int | None = None, depth: int = 3):
+        import queue
+
+        self.path, self.world = path, world
+        self.max_reads, self.max_bases, self.full_header, self.max_sample = max_reads, max_bases, full_header, max_sample
+        pipes = [os.pipe() for _ in range(world)]
+        self.read_fds = [r for r, _ in pipes]
+        self._write_fds = [w for _, w in pipes]
+        for r in self.read_fds:
+            os.set_inheritable(r, True)
+        self._queues = [queue.Queue(maxsize=depth) for _ in range(world)]
+        self._threads: list[threading.Thread] = []
+        self.error: BaseException | None = None
+        self.n_reads = 0
+
+    def start(self) -> None:
+        """Call after the workers have been spawned (they inherited the read ends)."""
+        for r in self.read_fds:
+            os.close(r)
+        for i in range(self.world):
+            t = threading.Thread(target=self._writer, args=(i,), daemon=True)
+            t.start()
+            self._threads.append(t)
+        t = threading.Thread(target=self._reader, daemon=True)
+        t.start()
+        self._threads.append(t)
+
+    def _reader(self):
+        try:
+            seen = 0
+            with FastqReader(self.path, full_header=self.full_header) as rd:
+                for i, c in enumerate(rd.chunks(self.max_reads, self.max_bases)):
+                    if self.max_sample is not None and seen + c.n > self.max_sample:
+                        c = c.head(self.max_sample - seen)
+                    seen += c.n
+                    if c.n:
+                        own = FastqChunk(c.n, c.seq.copy(), c.qual.copy(), c.offsets.copy(), c._names.copy(),
+                                         c._name_offsets.copy(), None if c._name_len is None else c._name_len.copy())
+                        self._queues[i % self.world].put(own)
+                    if self.max_sample is not None and seen >= self.max_sample:
+                        break
+            self.n_reads = seen
+        except BaseException as e:
+            self.error = e
+        finally:
+            for q in self._queues:
+                q.put(None)
+
+    def _writer(self, i: int):
+        try:
+            with os.fdopen(self._write_fds[i], "wb", buffering=1 << 20) as fh:
+                while True:
+                    c = self._queues[i].get()
+                    if c is None:
+                        return
+                    write_chunk(fh, c)
+        except BrokenPipeError:
+            pass  # the worker died; wait_ranks reports it
+        except BaseException as e:
+            self.error = self.error or e
+
+    def join(self) -> None:
+        for t in self._threads:
+            t.join()
+        if self.error is not None:
+            raise self.error
+
+
+def worker_python() -> list[str]:
+    return [sys.executable]

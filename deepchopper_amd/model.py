@@ -30,7 +30,7 @@ class TokenClassificationModel:
         if ids.dtype not in (torch.int64, torch.uint8):
             ids = ids.to(torch.int64)
         q = input_quals.to(dev, torch.float32)
-        return self.net.forward(ids.contiguous(), q.contiguous())
+        return self.net.forward_checked(ids.contiguous(), q.contiguous())  # fp16x3 range guard + bf16x6 redo
 
     __call__ = forward
 

@@ -113,7 +113,7 @@ def kmer_vectorize_targets(ranges: torch.Tensor, width: int) -> torch.Tensor:
 # smoothing / intervals
 # ------------------------------------------------------------------------------------------
 def smooth_intervals_from_logits(logits, first, length, *, window=21, min_interval=13, approved=20,
-                                 max_intervals=None, want_labels=True, out_offsets=None):
+                                 max_intervals=None, want_labels=True, out_offsets=None, total: int | None = None):
     """logits f32[n_rows, row_stride, 2]; first/length int32[n].  Returns dict with pred / smooth
     (ragged int8 at out_offsets), intervals [n, max_intervals, 2], n_intervals, keep, n_keep."""
     n = first.numel()
@@ -123,7 +123,10 @@ def smooth_intervals_from_logits(logits, first, length, *, window=21, min_interv
     if want_labels and out_offsets is None:
         out_offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         out_offsets[1:] = torch.cumsum(length.to(torch.int64), 0)
-    total = int(out_offsets[-1].item()) if want_labels else 0
+    if not want_labels:
+        total = 0
+    elif total is None:  # callers that know the host-side sum pass it: reading it back would block on the forward
+        total = int(out_offsets[-1].item())
     pred = torch.empty(total, dtype=torch.int8, device=dev) if want_labels else None
     smooth = torch.empty(total, dtype=torch.int8, device=dev) if want_labels else None
     iv = torch.zeros((n, max_intervals, 2), dtype=torch.int32, device=dev)
@@ -174,6 +177,9 @@ def summary_predict_dense(pred: torch.Tensor, labels: torch.Tensor, ignore_label
 # ------------------------------------------------------------------------------------------
 # model handle
 # ------------------------------------------------------------------------------------------
+GEMM_MODES = ("f32", "bf16x6", "fp16x3")
+
+
 class HipModel:
     """Owns a `dc_model*` (weights repacked on the device, filters, workspace)."""
 
@@ -235,10 +241,9 @@ class HipModel:
         handle = C.c_void_p()
         _lib.check(_lib.lib().dc_model_create(C.byref(c), C.byref(w), C.byref(handle)))
         self._h = handle
-        import os as _os
-
-        self.gemm_mode = {"f32": "f32", "0": "f32", "bf16x6": "bf16x6", "1": "bf16x6"}.get(
-            _os.environ.get("DC_GEMM_MODE", ""), "fp16x3")
+        mode = C.c_int32()
+        _lib.check(_lib.lib().dc_model_get_gemm_mode(self._h, C.byref(mode)))  # $DC_GEMM_MODE is parsed by the library only
+        self.gemm_mode = GEMM_MODES[mode.value]
         del keep
 
     def close(self):
@@ -274,6 +279,44 @@ class HipModel:
             self._h, _stream(), _ptr(input_ids), int(input_ids.dtype == torch.int64), _ptr(input_quals), n, row_stride,
             first.ctypes.data_as(C.POINTER(C.c_int32)), n_tokens.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
         return out
+
+    def head_forward(self, hidden: torch.Tensor, input_quals: torch.Tensor) -> torch.Tensor:
+        """Diagnostic: final LayerNorm + head on a residual stream f32[B, L, d_model] -> logits f32[B, L, 2]."""
+        assert hidden.dim() == 3 and hidden.shape[:2] == input_quals.shape and hidden.shape[2] == self.cfg.d_model
+        assert hidden.dtype == torch.float32 and input_quals.dtype == torch.float32
+        B, L, _ = hidden.shape
+        out = torch.empty((B, L, self.cfg.num_class), dtype=torch.float32, device=hidden.device)
+        _lib.check(_lib.lib().dc_head_forward(self._h, _stream(), _ptr(hidden), _ptr(input_quals), B, L, _ptr(out)))
+        return out
+
+    def forward_checked(self, input_ids, input_quals, first: np.ndarray | None = None, n_tokens: np.ndarray | None = None):
+        """forward / forward_ragged with the fp16x3 range guard consulted: if an activation left the fp16 range
+        the batch is re-run with the bf16 split (fp32 exponent range).  Synchronises the stream in fp16x3 mode;
+        pipelined callers attribute the guard per batch themselves (`set_overflow_target`)."""
+        run = (lambda: self.forward(input_ids, input_quals)) if first is None else (
+            lambda: self.forward_ragged(input_ids, input_quals, first, n_tokens))
+        if self.gemm_mode != "fp16x3":
+            return run()
+        counter = torch.zeros(1, dtype=torch.int32, device=input_ids.device)
+        self.set_overflow_target(counter)
+        try:
+            out = run()
+        finally:
+            self.set_overflow_target(None)
+        if int(counter.item()) > 0:
+            self.set_gemm_mode("bf16x6")
+            try:
+                out = run()
+            finally:
+                self.set_gemm_mode("fp16x3")
+        return out
+
+    def set_overflow_target(self, counter: torch.Tensor | None):
+        """Route the fp16x3 range guard of the forwards launched from now on into `counter` (int32[1] on the
+        device, zeroed by the caller); None restores the handle's own counter."""
+        if counter is not None:
+            assert counter.is_cuda and counter.dtype == torch.int32 and counter.numel() >= 1
+        _lib.check(_lib.lib().dc_model_set_overflow_target(self._h, _ptr(counter)))
 
     def filter(self, layer: int, seq_len: int) -> torch.Tensor:
         out = torch.empty((self.cfg.d_model, seq_len), dtype=torch.float32, device=_dev())

@@ -11,12 +11,15 @@ receives labels / intervals (and, when asked for, the reference's `.pt` wire for
 from __future__ import annotations
 
 import os
+import queue
+import threading
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
 from . import ops
+from .fastq import decode_names
 from .tokenizer import DEFAULT_MAX_LENGTH, check_read_status, encode_ids_int8
 
 
@@ -32,6 +35,33 @@ class SmoothParams:
     min_read_len: int = 150
 
 
+class _Pinned:
+    """Page-locked host buffers that grow on demand, one per key: H2D / D2H copies from / into them are
+    asynchronous, so no copy of the pipeline blocks the host on GPU work."""
+
+    def __init__(self):
+        self._buf: dict[str, torch.Tensor] = {}
+
+    def get(self, key: str, nbytes: int) -> torch.Tensor:
+        b = self._buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
+            self._buf[key] = b
+        return b[:nbytes]
+
+    def array(self, key: str, shape, dtype) -> np.ndarray:
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.get(key, n).numpy().view(dtype).reshape(shape)
+
+
+class _Slot:
+    """Host side of one in-flight batch: pinned staging for its inputs and its results."""
+
+    def __init__(self):
+        self.pin = _Pinned()
+        self.n = 0
+
+
 class PredictPipeline:
     """tokenise -> forward -> smooth on device-resident batches."""
 
@@ -39,6 +69,7 @@ class PredictPipeline:
         self.model = model
         self.max_length = max_length
         self.smooth = smooth or SmoothParams()
+        self._copy_stream = None
 
     # ---- stage 1 ---------------------------------------------------------------------
     def tokenize(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, max_len_bases: int,
@@ -49,34 +80,79 @@ class PredictPipeline:
 
     # ---- whole hot path on one device batch ---------------------------------------------
     def run_device_batch(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, lens_host: np.ndarray,
-                         *, reference_padding: bool = False, want_labels: bool = True, ids_i64: bool = False):
+                         *, reference_padding: bool = False, want_labels: bool = True, ids_i64: bool = False,
+                         staging: _Pinned | None = None):
         """seq/qual: concatenated raw bytes on the device; offsets int64[n+1] on the device;
         lens_host: read lengths (host copy, known from parsing).
 
         reference_padding=False (native): every read is run at its own length (== the reference
         at --batch-size 1).  reference_padding=True: the batch is left-padded to its longest read
-        and the pad tokens run through the model exactly as in the reference."""
+        and the pad tokens run through the model exactly as in the reference.
+
+        Every launch is asynchronous: the per-read index arrays go up in one copy BEFORE the forward is
+        launched (from `staging`, pinned, when given), and nothing is read back here."""
         n = int(lens_host.shape[0])
         max_len = int(lens_host.max())
-        tok = self.tokenize(seq, qual, offsets, max_len, pad_left=True, ids_i64=ids_i64, want_labels=want_labels)
-        row_stride = tok["input_ids"].shape[1]
+        row_stride = min(max_len, self.max_length - 1) + 1
         ntok = np.minimum(lens_host, self.max_length - 1).astype(np.int32) + 1
         first = (row_stride - ntok).astype(np.int32)
+        # one small H2D for smoothing's per-read arrays: int64 out_offsets[n+1] | int32 first[n] | int32 len[n]
+        nb = 8 * (n + 1) + 8 * n
+        host = staging.get("aux", nb).numpy() if staging is not None else np.empty(nb, np.uint8)
+        oo = host[: 8 * (n + 1)].view(np.int64)
+        oo[0] = 0
+        np.cumsum(ntok - 1, out=oo[1:])
+        total = int(oo[n])
+        host[8 * (n + 1): 8 * (n + 1) + 4 * n].view(np.int32)[:] = first
+        host[8 * (n + 1) + 4 * n:].view(np.int32)[:] = ntok - 1
+        d_aux = torch.empty(nb, dtype=torch.uint8, device=seq.device)
+        d_aux.copy_(torch.from_numpy(host) if staging is None else staging.get("aux", nb), non_blocking=staging is not None)
+        out_offsets = d_aux[: 8 * (n + 1)].view(torch.int64)
+        d_first = d_aux[8 * (n + 1): 8 * (n + 1) + 4 * n].view(torch.int32)
+        d_len = d_aux[8 * (n + 1) + 4 * n:].view(torch.int32)
+
+        tok = self.tokenize(seq, qual, offsets, max_len, pad_left=True, ids_i64=ids_i64, want_labels=want_labels)
+        assert tok["input_ids"].shape[1] == row_stride
         if reference_padding or bool(np.all(ntok == row_stride)):
             logits = self.model.net.forward(tok["input_ids"], tok["input_quals"])
         else:
             logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
-        d_first = ops.to_device(first)
-        d_len = ops.to_device((ntok - 1).astype(np.int32))
-        out_offsets = None
-        if want_labels:
-            oo = np.zeros(n + 1, np.int64)
-            np.cumsum(ntok - 1, out=oo[1:])
-            out_offsets = ops.to_device(oo)
         sp = self.smooth
         sm = ops.smooth_intervals_from_logits(logits, d_first, d_len, window=sp.window, min_interval=sp.min_interval,
-                                              approved=sp.approved, want_labels=want_labels, out_offsets=out_offsets)
-        return {"tok": tok, "logits": logits, "smooth": sm, "first": first, "n_tokens": ntok}
+                                              approved=sp.approved, want_labels=want_labels,
+                                              out_offsets=out_offsets if want_labels else None, total=total)
+        if not want_labels:
+            sm["offsets"] = out_offsets
+        return {"tok": tok, "logits": logits, "smooth": sm, "first": first, "n_tokens": ntok, "offsets_host": oo.copy()}
+
+    def run_checked(self, seq, qual, offsets, lens_host, **kw):
+        """run_device_batch with the fp16x3 range guard consulted (synchronises): a batch in which an activation
+        left the fp16 range is re-run with the bf16 split (fp32 exponent range)."""
+        net = self.model.net
+        if net.gemm_mode != "fp16x3":
+            res = self.run_device_batch(seq, qual, offsets, lens_host, **kw)
+            torch.cuda.current_stream().synchronize()
+            return res
+        counter = torch.zeros(1, dtype=torch.int32, device=seq.device)
+        net.set_overflow_target(counter)
+        try:
+            res = self.run_device_batch(seq, qual, offsets, lens_host, **kw)
+        finally:
+            net.set_overflow_target(None)
+        if int(counter.item()) > 0:
+            res = self._rerun_bf16x6(seq, qual, offsets, lens_host, **kw)
+        return res
+
+    def _rerun_bf16x6(self, seq, qual, offsets, lens_host, **kw):
+        net = self.model.net
+        net.set_gemm_mode("bf16x6")
+        try:
+            res = self.run_device_batch(seq, qual, offsets, lens_host, **kw)
+            torch.cuda.current_stream().synchronize()
+        finally:
+            net.set_gemm_mode("fp16x3")
+        res["range_guard_rerun"] = True
+        return res
 
     # ---- host-facing convenience -----------------------------------------------------------
     def predict_reads(self, ids: list[str], seqs: list[bytes], quals: list[bytes], *, reference_padding: bool = False):
@@ -90,20 +166,11 @@ class PredictPipeline:
         qb, _ = ops.pack_reads(quals)
         lens = np.diff(offs)
         d_seq, d_qual, d_offs = ops.to_device(sb), ops.to_device(qb), ops.to_device(offs)
-        res = self.run_device_batch(d_seq, d_qual, d_offs, lens, reference_padding=reference_padding)
-        torch.cuda.synchronize()
-        net = self.model.net
-        if net.gemm_mode == "fp16x3" and net.overflow() > 0:
-            # an activation left the fp16 range: redo the batch with the bf16 split (fp32 exponent range)
-            net.set_gemm_mode("bf16x6")
-            try:
-                res = self.run_device_batch(d_seq, d_qual, d_offs, lens, reference_padding=reference_padding)
-                torch.cuda.synchronize()
-            finally:
-                net.set_gemm_mode("fp16x3")
-        check_read_status(res["tok"]["status"].cpu().numpy(), ids)
+        res = self.run_checked(d_seq, d_qual, d_offs, lens, reference_padding=reference_padding)
+        status = res["tok"]["status"].cpu().numpy()
+        check_read_status(status, ids)
         sm = res["smooth"]
-        o = sm["offsets"].cpu().numpy()
+        o = res["offsets_host"]
         pred, smooth = sm["pred"].cpu().numpy(), sm["smooth"].cpu().numpy()
         iv, niv = sm["intervals"].cpu().numpy(), sm["n_intervals"].cpu().numpy()
         kp, nkp = sm["keep"].cpu().numpy(), sm["n_keep"].cpu().numpy()
@@ -115,55 +182,67 @@ class PredictPipeline:
                 "smooth": smooth[o[r]: o[r + 1]],
                 "intervals": [tuple(x) for x in iv[r, : niv[r]].tolist()],
                 "keep": [tuple(x) for x in kp[r, : nkp[r]].tolist()],
-                "is_truncated": bool(res["tok"]["status"][r].item() & 1),
+                "is_truncated": bool(status[r] & 1),
             })
         return out, res
 
-
     # ---- streaming: FASTQ chunks -> labels / intervals, host I/O overlapped with GPU work ---------------
-    def _collect(self, names, lens, seq_h, qual_h, offs_h, d_in, res):
-        """D2H of one finished batch (blocks until the GPU is done with it)."""
-        net = self.model.net
-        torch.cuda.current_stream().synchronize()
-        if net.gemm_mode == "fp16x3" and net.overflow() > 0:
-            net.set_gemm_mode("bf16x6")  # an activation left the fp16 range: redo with the fp32-range split
-            try:
-                res = self.run_device_batch(*d_in, lens)
-                torch.cuda.current_stream().synchronize()
-            finally:
-                net.set_gemm_mode("fp16x3")
-        status = res["tok"]["status"].cpu().numpy()
-        check_read_status(status, names)
-        sm = res["smooth"]
-        return {
-            "names": names, "lengths": lens, "seq": seq_h, "qual": qual_h, "in_offsets": offs_h,
-            "offsets": sm["offsets"].cpu().numpy(), "pred": sm["pred"].cpu().numpy(), "smooth": sm["smooth"].cpu().numpy(),
-            "intervals": sm["intervals"].cpu().numpy(), "n_intervals": sm["n_intervals"].cpu().numpy(),
-            "keep": sm["keep"].cpu().numpy(), "n_keep": sm["n_keep"].cpu().numpy(), "truncated": (status & 1) != 0,
-            "device": res,  # device-resident tensors of the batch (logits, token matrices) for write_pt_batch
-        }
-
-    def predict_stream(self, chunks, *, prefetch: int = 2):
+    def predict_stream(self, chunks, *, prefetch: int = 2, want_labels: bool = True, reference_padding: bool = False,
+                       ids_i64: bool = False, borrow: bool = False, want_names: bool = True):
         """`chunks`: an iterator of fastq.FastqChunk (e.g. `FastqReader.chunks(max_reads, max_tokens)`).
-        Yields one result dict per chunk, in input order: names, lengths, packed per-base labels
-        (`pred`, `smooth` + `offsets`), `intervals` / `n_intervals`, `keep` / `n_keep`, `truncated`.
+        Yields one result dict per chunk, in input order: `names`, `lengths`, packed per-base labels
+        (`pred`, `smooth` + `offsets`; only with want_labels), `intervals` / `n_intervals`, `keep` / `n_keep`,
+        `truncated`, `pred_len`, the chunk's host buffers (`seq`, `qual`, `in_offsets`, `headers`,
+        `header_offsets`, `name_len`) and `device` (the batch's device tensors, for `write_pt_batch`).
 
-        Three things overlap: a helper thread parses (and inflates) the next chunks; the GPU runs batch k
-        (all launches are asynchronous); the host collects and hands out batch k-1.  Every read runs at
-        its own length (native mode, == the reference at --batch-size 1)."""
-        import queue
-        import threading
+        Four things overlap: a helper thread parses (and inflates) the next chunks straight into pinned
+        staging; the compute stream runs batch k (tokenise, forward, smoothing: all launches asynchronous,
+        inputs uploaded by non-blocking copies); a copy stream brings batch k-1's results into pinned host
+        memory; the host hands out batch k-2... i.e. the only wait is for a batch's own copy event.
+        The fp16x3 range guard is attributed per batch: every batch has its own device counter, read back with
+        its results, so a batch launched while an earlier one is collected cannot lose (or lend) its overflow.
 
+        borrow=True: the yielded host arrays are views into pinned staging that is reused once the consumer
+        asks for the next result (the fused chop driver consumes them at once); otherwise they are copies."""
+        net = self.model.net
+        dev = torch.device("cuda", torch.cuda.current_device())
+        compute = torch.cuda.current_stream()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream()
+        copy_stream = self._copy_stream
+        n_slots = max(1, prefetch) + 3
+        free: queue.Queue = queue.Queue()
+        for _ in range(n_slots):
+            free.put(_Slot())
         q: queue.Queue = queue.Queue(maxsize=max(1, prefetch))
         stop = threading.Event()
 
         def produce():
             try:
                 for c in chunks:
-                    item = (c.names(), c.lengths.copy(), c.seq.copy(), c.qual.copy(), c.offsets.copy())
+                    slot = None
+                    while slot is None and not stop.is_set():
+                        try:
+                            slot = free.get(timeout=0.1)
+                        except queue.Empty:
+                            continue
+                    if stop.is_set():
+                        return
+                    n, nb = c.n, int(c.offsets[c.n])
+                    slot.n = n
+                    slot.seq = slot.pin.array("seq", (nb,), np.uint8)
+                    slot.qual = slot.pin.array("qual", (nb,), np.uint8)
+                    slot.offs = slot.pin.array("offs", (n + 1,), np.int64)
+                    slot.seq[:] = c.seq
+                    slot.qual[:] = c.qual
+                    slot.offs[:] = c.offsets
+                    slot.headers = np.array(c._names, copy=True)
+                    slot.header_offsets = np.array(c._name_offsets, copy=True)
+                    slot.name_len = None if c._name_len is None else np.array(c._name_len, copy=True)
+                    slot.lens = np.diff(slot.offs)
                     while not stop.is_set():
                         try:
-                            q.put(item, timeout=0.1)
+                            q.put(slot, timeout=0.1)
                             break
                         except queue.Full:
                             continue
@@ -173,6 +252,73 @@ class PredictPipeline:
             except BaseException as e:  # surfaces in the consumer
                 q.put(e)
 
+        def launch(slot: _Slot):
+            n, nb = slot.n, int(slot.offs[slot.n])
+            d_seq = torch.empty(nb, dtype=torch.uint8, device=dev)
+            d_qual = torch.empty(nb, dtype=torch.uint8, device=dev)
+            d_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            d_seq.copy_(slot.pin.get("seq", nb), non_blocking=True)
+            d_qual.copy_(slot.pin.get("qual", nb), non_blocking=True)
+            d_offs.copy_(slot.pin.get("offs", 8 * (n + 1)).view(torch.int64), non_blocking=True)
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            guard = net.gemm_mode == "fp16x3"
+            if guard:
+                net.set_overflow_target(counter)
+            try:
+                res = self.run_device_batch(d_seq, d_qual, d_offs, slot.lens, reference_padding=reference_padding,
+                                            want_labels=want_labels, ids_i64=ids_i64, staging=slot.pin)
+            finally:
+                if guard:
+                    net.set_overflow_target(None)
+            done = torch.cuda.Event()
+            done.record(compute)
+            # results -> pinned host memory on the copy stream
+            sm = res["smooth"]
+            outs = {"status": res["tok"]["status"], "guard": counter, "intervals": sm["intervals"],
+                    "n_intervals": sm["n_intervals"], "keep": sm["keep"], "n_keep": sm["n_keep"]}
+            if want_labels:
+                outs["pred"], outs["smooth"] = sm["pred"], sm["smooth"]
+            host = {}
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                for k, t in outs.items():
+                    hb = slot.pin.get("out_" + k, t.numel() * t.element_size())
+                    hb.view(t.dtype).view(t.shape).copy_(t, non_blocking=True) if t.numel() else None
+                    host[k] = hb.numpy().view(_NP[t.dtype]).reshape(tuple(t.shape))
+                copied = torch.cuda.Event()
+                copied.record(copy_stream)
+            return {"slot": slot, "res": res, "d_in": (d_seq, d_qual, d_offs), "host": host, "copied": copied}
+
+        def collect(b):
+            slot, res, host = b["slot"], b["res"], b["host"]
+            b["copied"].synchronize()
+            if int(host["guard"][0]) > 0:  # this batch (and only this one) left the fp16 range: redo it in bf16x6
+                res = self._rerun_bf16x6(*b["d_in"], slot.lens, reference_padding=reference_padding,
+                                         want_labels=want_labels, ids_i64=ids_i64)
+                sm = res["smooth"]
+                host = {"status": res["tok"]["status"].cpu().numpy(), "intervals": sm["intervals"].cpu().numpy(),
+                        "n_intervals": sm["n_intervals"].cpu().numpy(), "keep": sm["keep"].cpu().numpy(),
+                        "n_keep": sm["n_keep"].cpu().numpy()}
+                if want_labels:
+                    host["pred"], host["smooth"] = sm["pred"].cpu().numpy(), sm["smooth"].cpu().numpy()
+            own = (lambda a: a) if borrow else (lambda a: np.array(a, copy=True))
+            status = host["status"]
+            names = decode_names(slot.headers, slot.header_offsets, slot.name_len, slot.n) if want_names else None
+            if (status & 2).any():
+                check_read_status(status, names or decode_names(slot.headers, slot.header_offsets, slot.name_len, slot.n))
+            out = {
+                "names": names, "lengths": slot.lens, "seq": own(slot.seq), "qual": own(slot.qual), "in_offsets": own(slot.offs),
+                "headers": slot.headers, "header_offsets": slot.header_offsets, "name_len": slot.name_len,
+                "offsets": res["offsets_host"], "pred_len": (res["n_tokens"] - 1).astype(np.int32),
+                "intervals": own(host["intervals"]), "n_intervals": own(host["n_intervals"]),
+                "keep": own(host["keep"]), "n_keep": own(host["n_keep"]), "truncated": (status & 1) != 0,
+                "range_guard_rerun": bool(res.get("range_guard_rerun", False)),
+                "device": res,  # device-resident tensors of the batch (logits, token matrices) for write_pt_batch
+            }
+            if want_labels:
+                out["pred"], out["smooth"] = own(host["pred"]), own(host["smooth"])
+            return out
+
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         pending = None
@@ -181,20 +327,19 @@ class PredictPipeline:
                 item = q.get()
                 if isinstance(item, BaseException):
                     raise item
-                if item is not None:
-                    names, lens, seq_h, qual_h, offs_h = item
-                    d_in = (ops.to_device(seq_h), ops.to_device(qual_h), ops.to_device(offs_h))
-                    launched = (names, lens, seq_h, qual_h, offs_h, d_in, self.run_device_batch(*d_in, lens))
-                else:
-                    launched = None
+                launched = launch(item) if item is not None else None
                 if pending is not None:
-                    yield self._collect(*pending)
+                    yield collect(pending)
+                    free.put(pending["slot"])  # the consumer is done with the borrowed views
                 pending = launched
                 if item is None:
                     break
         finally:
             stop.set()
             th.join(timeout=5)
+
+
+_NP = {torch.int8: np.int8, torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32}
 
 
 def write_pt_batch(path: str, res: dict, ids: list[str]) -> None:

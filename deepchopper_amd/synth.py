@@ -89,3 +89,50 @@ def to_fastq(seqs, quals, ids) -> bytes:
         qb = q.tobytes() if hasattr(q, "tobytes") else bytes(q)
         out.append(b"@" + i.encode() + b"\n" + sb + b"\n+\n" + qb + b"\n")
     return b"".join(out)
+
+
+def synth_nanopore_like(n_reads: int, seed: int = 42, start_index: int = 0, median_len: float = 900.0,
+                        sigma: float = 0.75, min_len: int = 100, max_len: int = 30000, gate: bytes = b"N"):
+    """Config C5 stand-in: a direct-RNA-like length mix (log-normal around `median_len`, clipped) with ONT-style
+    definition lines (`@id runid=... ch=... start_time=...`) and planted adapters written as runs of the `gate`
+    base -- the base `weights.token_gated_state_dict` labels 1 -- so that predict -> chop really chops:
+    60 % of the reads carry a 3' terminal adapter (40-80 bases at the very end), 6 % an internal one
+    (chimeric read), 2 % five internal ones (more than --mpi 4: passed through).  Bases iid uniform over ACGT (no natural `gate`
+    bases), qualities Phred 1..40.  Returns (headers, seqs, quals) as lists of bytes."""
+    u = uniform01(seed, n_reads, stream=20 + 4 * start_index)
+    z = np.sqrt(-2.0 * np.log(np.maximum(u, 1e-300))) * np.cos(2 * np.pi * uniform01(seed, n_reads, stream=21 + 4 * start_index))
+    lens = np.clip(np.exp(np.log(median_len) + sigma * z), min_len, max_len).astype(np.int64)
+    offs = np.zeros(n_reads + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    total = int(offs[-1])
+    # one splitmix64 output feeds eight bases: byte b -> base b & 3, Phred 1 + (b >> 2) % 40
+    r = splitmix64(seed, (total + 7) // 8, stream=22 + 4 * start_index).view(np.uint8)[:total]
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[r & np.uint8(3)]
+    qual = (np.uint8(34) + (r >> np.uint8(2)) % np.uint8(40)).astype(np.uint8)
+    kind = uniform01(seed, n_reads, stream=23 + 4 * start_index)
+    pick = splitmix64(seed, n_reads, stream=24 + 4 * start_index)
+    g = np.uint8(gate[0])
+    headers, seqs, quals = [], [], []
+    for i in range(n_reads):
+        a, L = int(offs[i]), int(lens[i])
+        k, p = kind[i], int(pick[i] & np.uint64(0x7FFFFFFF))
+        alen = 40 + p % 41
+        if k < 0.60 and L >= alen + 60:
+            bases[a + L - alen: a + L] = g
+        elif k < 0.66 and L >= alen + 200:
+            s = 60 + (p >> 8) % (L - alen - 120)
+            bases[a + s: a + s + alen] = g
+        elif k < 0.68 and L >= 700:
+            for j in range(5):
+                s = 40 + j * (L - 80) // 5
+                bases[a + s: a + s + 30] = g
+        gi = start_index + i
+        headers.append(b"read_%09d runid=%08x ch=%d start_time=2026-01-01T00:%02d:%02dZ" % (gi, p, 1 + p % 512, (gi // 60) % 60, gi % 60))
+        seqs.append(bases[a: a + L].tobytes())
+        quals.append(qual[a: a + L].tobytes())
+    return headers, seqs, quals
+
+
+def fastq_text(headers, seqs, quals) -> bytes:
+    """FASTQ text of records whose definition lines are given whole (bytes, without the '@')."""
+    return b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in zip(headers, seqs, quals))

@@ -129,6 +129,45 @@ def synthetic_state_dict(seed: int = 0, cfg: HyenaDNAConfig | None = None) -> di
     return sd
 
 
+def token_gated_state_dict(seed: int = 0, token_id: int = 11, backbone_gain: float = 0.003,
+                            cfg: HyenaDNAConfig | None = None) -> dict[str, np.ndarray]:
+    """Synthetic weights whose per-base label is a DESIGNED function of the input: label 1 exactly where the
+    base's token is `token_id` (default 11 = 'N'), with a logit margin of ~1 -- far above any arithmetic noise.
+    For flow tests and end-to-end benchmarks of predict -> chop, where adapters are planted as runs of that
+    base and the expected records must not depend on near-tie logits.  Same shapes, same kernels: the
+    embedding rows are Walsh functions (mean 0, variance 1, mutually orthogonal), the backbone blocks keep
+    their seeded weights but write into the residual stream with a small gain, and the head reads the token
+    off the final LayerNorm output (linear1 = matched filters with a -0.5 bias, linear2 = 0 so that its
+    residual + ReLU passes linear1's output on, linear3 picks the gate unit)."""
+    cfg = cfg or HyenaDNAConfig()
+    sd = synthetic_state_dict(seed, cfg)
+    D, HH = cfg.d_model, cfg.head_hidden
+    assert D & (D - 1) == 0 and cfg.padded_vocab < D
+    h = np.array([[1.0]])
+    while h.shape[0] < D:
+        h = np.block([[h, h], [h, -h]])
+    emb = h[1: cfg.padded_vocab + 1].astype(np.float32)  # row 0 (all ones) has no variance
+    sd[BB + "embeddings.word_embeddings.weight"] = emb
+    for i in range(cfg.n_layer):
+        p = BB + f"layers.{i}."
+        for k in ("mixer.out_proj.weight", "mixer.out_proj.bias", "mlp.fc2.weight", "mlp.fc2.bias"):
+            sd[p + k] = (sd[p + k] * backbone_gain).astype(np.float32)
+    sd[BB + "ln_f.weight"] = np.ones(D, np.float32)
+    sd[BB + "ln_f.bias"] = np.zeros(D, np.float32)
+    w1 = np.zeros((HH, D), np.float32)
+    b1 = np.zeros(HH, np.float32)
+    w1[: cfg.padded_vocab] = emb / D
+    b1[: cfg.padded_vocab] = -0.5
+    sd[HD + "linear1.weight"], sd[HD + "linear1.bias"] = w1, b1
+    sd[HD + "linear2.weight"] = np.zeros((HH, HH), np.float32)
+    sd[HD + "linear2.bias"] = np.zeros(HH, np.float32)
+    w3 = np.zeros((cfg.num_class, HH), np.float32)
+    w3[1, token_id] = 4.0
+    sd[HD + "linear3.weight"] = w3
+    sd[HD + "linear3.bias"] = np.array([1.0, 0.0], np.float32)[: cfg.num_class]
+    return sd
+
+
 def _strip(sd: dict) -> dict[str, np.ndarray]:
     out = {}
     for k, v in sd.items():

@@ -230,6 +230,16 @@ int dc_forward_ragged(dc_model* m, void* stream, const void* d_input_ids, int32_
                       const float* d_input_quals, int32_t n_reads, int64_t row_stride,
                       const int32_t* h_first, const int32_t* h_n_tokens, float* d_logits);
 
+/* Diagnostic: the tail of the forward alone -- final LayerNorm + TokenClassificationHead.forward
+ * (deepchopper/models/llm/head.py:75-102) -- on a caller-supplied residual stream
+ * d_hidden float[batch, seq_len, d_model] (the backbone's last hidden state BEFORE ln_f, token-major as the
+ * reference holds it) and d_input_quals float[batch, seq_len]; logits float[batch, seq_len, num_class].
+ * Runs the same kernels as dc_forward (LayerNorm statistics, linear1 + ReLU + quality, linear2 + residual +
+ * ReLU fused with linear3) in the GEMM mode in force; lets the head be checked directly against vectors
+ * produced by the reference's own head.py (tests/golden/make_head_golden.py). */
+int dc_head_forward(dc_model* m, void* stream, const float* d_hidden, const float* d_input_quals, int32_t batch,
+                    int32_t seq_len, float* d_logits);
+
 /* Device bytes currently held by the handle (weights + filters + workspace). */
 int64_t dc_model_device_bytes(const dc_model* m);
 
@@ -265,6 +275,18 @@ int dc_model_set_mlp_fusion(dc_model* m, int32_t level);
  * value since the last call and clears the counter; callers re-run the batch in mode 1 when it is non-zero
  * (deepchopper_amd/predict.py does). */
 int dc_model_overflow(dc_model* m, void* stream, int32_t* count);
+
+/* Per-batch attribution of the range guard for pipelined callers.  While a non-NULL caller-owned device
+ * counter is set, every forward launched afterwards bumps THAT int32 (the caller zeroes it, and reads it
+ * back once the batch has finished -- e.g. with the batch's other results on a copy stream) instead of
+ * the handle's own counter, so a batch launched while an earlier one is still being collected cannot
+ * have its overflow consumed, or cleared, by the earlier batch's check.  NULL restores the handle's
+ * counter (dc_model_overflow). */
+int dc_model_set_overflow_target(dc_model* m, int32_t* d_counter);
+
+/* The GEMM mode in force (0 / 1 / 2 as dc_model_set_gemm_mode): the one place $DC_GEMM_MODE is parsed is
+ * dc_model_create; bindings read the result here instead of parsing the variable again. */
+int dc_model_get_gemm_mode(const dc_model* m, int32_t* mode);
 
 /* Per-stage device timing with HIP events recorded on the stream the kernels are launched on.
  * While enabled, every kernel launch of dc_forward / dc_forward_ragged is bracketed by an event

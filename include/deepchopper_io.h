@@ -79,6 +79,15 @@ int dc_fq_open_range(const char* path, int64_t byte_begin, int64_t byte_end, int
 int dc_fq_read_chunk(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
                      int64_t* offsets, char* names, int64_t cap_names, int64_t* name_offsets, int64_t* n_reads);
 
+/* Same, but `headers` receives the WHOLE definition line after '@' (name, delimiter, description; CR
+ * stripped) and name_len[r] the length of its name part.  The chop stage needs both: records that pass
+ * through unchanged keep their description (process_chunk returns fq_record.clone(),
+ * src/bin/predict.rs:146-164, and the noodles writer emits "@name description"), chopped records are
+ * named from the name part alone (Definition::new(id, ""), src/output/split.rs:213-221). */
+int dc_fq_read_chunk_full(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint8_t* qual, int64_t cap_bases,
+                          int64_t* offsets, char* headers, int64_t cap_headers, int64_t* header_offsets,
+                          int32_t* name_len, int64_t* n_reads);
+
 /* records delivered so far / compressed-or-plain bytes consumed so far */
 int64_t dc_fq_records_read(const dc_fq_reader* r);
 int64_t dc_fq_bytes_consumed(const dc_fq_reader* r);
@@ -97,6 +106,42 @@ int dc_bgzf_write_fastq(dc_bgzf_writer* w, int64_t n, const char* names, const i
                         const uint8_t* seq, const uint8_t* qual, const int64_t* offsets);
 /* flushes, appends the 28-byte BGZF EOF block, closes the file and frees the handle */
 int dc_bgzf_close(dc_bgzf_writer* w);
+
+/* ---- chop stage of the fused predict -> chop flow ------------------------------------------------
+ * One call per reader chunk: the gating of process_chunk (src/bin/predict.rs:130-192), the record
+ * splitting of split_noodle_records_by_remove_intervals (src/output/split.rs:171-226) or, with
+ * output_chopped_seqs, split_noodle_records_by_intervals (src/output/split.rs:138-169), and the FASTQ
+ * text of every resulting record written to `w`.  Replaces the reference's `.pt` round trip
+ * (callbacks.py:12-25 -> load_predicts_from_batch_pts, src/bin/predict.rs:222-235) for the case where
+ * predict and chop run in one process: the per-read inputs are what dc_smooth_intervals_from_logits
+ * (deepchopper_hip.h) leaves on the device, copied to the host by the caller. */
+typedef struct dc_chop_params {
+  int32_t min_read_len;               /* default::MIN_READ_LEN = 150 (src/default.rs)                 */
+  int32_t max_process_intervals;      /* --mpi, 4                                                      */
+  int32_t min_read_length_after_chop; /* --mcr, 20                                                     */
+  int32_t chop_type;                  /* --ct: 0 terminal, 1 internal, 2 all                           */
+  int32_t output_chopped_seqs;        /* --ocq: emit the chopped segments instead of the kept ones     */
+  int32_t id_annotation;              /* "|T" / "|I" suffix (process_chunk passes true)                */
+} dc_chop_params;
+
+/*   headers / header_offsets / name_len   as dc_fq_read_chunk_full delivers them (name_len NULL: every
+ *                                         header is a bare name)
+ *   seq / qual / offsets                  the chunk's packed reads (raw FASTQ bytes)
+ *   pred_len     int32[n]                 length of the prediction (= tokens - 1); a read whose prediction
+ *                                         is shorter than the read (truncated) passes through unchanged
+ *   n_intervals  int32[n], intervals int32[n][max_intervals][2]   smoothed, selected intervals (0 = none /
+ *                                         more than the approved number)
+ *   n_keep       int32[n], keep int32[n][max_keep][2]             complement segments (generate_unmaped_intervals)
+ *   records_per_read  int32[n] or NULL    records written for each read
+ * Chopped records take their bases from the prediction's sequence as the reference does (Predict.seq =
+ * id_list2seq(tokens): upper-case ACGT, U -> T, anything else N); pass-through records are the input
+ * record byte for byte. */
+int dc_chop_write_chunk(dc_bgzf_writer* w, const dc_chop_params* p, int64_t n, const char* headers,
+                        const int64_t* header_offsets, const int32_t* name_len, const uint8_t* seq,
+                        const uint8_t* qual, const int64_t* offsets, const int32_t* pred_len,
+                        const int32_t* n_intervals, const int32_t* intervals, int32_t max_intervals,
+                        const int32_t* n_keep, const int32_t* keep, int32_t max_keep,
+                        int32_t* records_per_read, int64_t* n_records_out);
 
 #ifdef __cplusplus
 }

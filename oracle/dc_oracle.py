@@ -734,6 +734,12 @@ def split_records_by_remove_intervals(
     return out
 
 
+def split_records_by_intervals(seq: bytes, rid: bytes, qual: bytes, target: Sequence[tuple[int, int]]):
+    """split_noodle_records_by_intervals (src/output/split.rs:138-169), the `--ocq` form: one record per
+    interval, id `{id}|{start}:{end}`, no annotation, no length filter."""
+    return [(rid + b"|%d:%d" % (s, e), seq[s:e], qual[s:e]) for s, e in target]
+
+
 # --------------------------------------------------------------------------------------
 # S4  chop gating                                        src/bin/predict.rs:130-192
 # --------------------------------------------------------------------------------------
@@ -748,9 +754,15 @@ def chop_read(
     max_process_intervals=4,
     min_read_length_after_chop=20,
     chop_type="all",
+    output_chopped_seqs=False,
+    fq_header: bytes | None = None,
 ):
-    """One iteration of `process_chunk` (default `--ocq` off).  Returns the output records."""
-    orig = [(fq_id, fq_seq, fq_qual)]
+    """One iteration of `process_chunk`.  Returns the output records as (definition line, seq, qual).
+
+    `fq_header`: the record's whole definition line (name + description).  Records that pass through are
+    `fq_record.clone()` (predict.rs:146-164) and the noodles FASTQ writer emits `@name description`; records
+    built by the split functions carry `Definition::new(id, "")`, i.e. the bare name."""
+    orig = [(fq_header if fq_header is not None else fq_id, fq_seq, fq_qual)]
     if predict.seq_len() < MIN_READ_LEN:
         return orig
     ivs = predict.smooth_and_select_intervals(smooth_window_size, min_interval_size, approved_interval_number)
@@ -758,6 +770,8 @@ def chop_read(
         return orig
     if predict.seq_len() != len(fq_qual):
         return orig
+    if output_chopped_seqs:
+        return split_records_by_intervals(predict.seq.encode(), fq_id, fq_qual, ivs)
     return split_records_by_remove_intervals(
         predict.seq.encode(), fq_id, fq_qual, ivs, min_read_length_after_chop, True, chop_type
     )

@@ -115,20 +115,25 @@ def test_forward_ragged_equals_per_read_oracle(env):
 
 
 def test_head_against_reference_golden(env, golden_dir):
-    """F3 pinned by vectors generated from the reference's own head.py: feed the golden `x` as
-    the backbone output by making the backbone an identity (zero blocks, unit LayerNorm)."""
+    """F3 pinned on the GPU by vectors generated from the reference's own head.py
+    (deepchopper/models/llm/head.py:75-102, tests/golden/make_head_golden.py): the golden residual stream goes
+    through the HIP final-LayerNorm + head kernels (`dc_head_forward`, the same launches dc_forward ends with)
+    in the GEMM mode of the fixture and must reproduce the reference's logits."""
     torch, ops, sd, model = env
-    from oracle import forward_ref as fr
-    from deepchopper_amd.weights import HD, synthetic_state_dict
+    from deepchopper_amd.weights import BB, HD, HyenaDNAConfig, synthetic_state_dict
 
     g = np.load(os.path.join(golden_dir, "head_golden.npz"))
-    sd7 = synthetic_state_dict(seed=7)
+    sd7 = dict(synthetic_state_dict(seed=7))
     chk = np.array([float(np.sum(sd7[HD + f"{n}.weight"].astype(np.float64))) for n in ("linear1", "linear2", "linear3")])
     np.testing.assert_allclose(chk, g["weight_checksums"], rtol=1e-12)
-    # oracle head == reference head (CPU)
-    tsd = {k: torch.as_tensor(v) for k, v in sd7.items()}
-    ref = fr.head_forward(tsd, torch.as_tensor(g["x"]), torch.as_tensor(g["quals"])).numpy()
-    np.testing.assert_allclose(ref, g["logits"], rtol=0, atol=1e-5)
+    sd7[BB + "ln_f.weight"], sd7[BB + "ln_f.bias"] = g["ln_f_weight"], g["ln_f_bias"]
+    m7 = ops.HipModel(sd7, HyenaDNAConfig())
+    m7.set_gemm_mode(model.gemm_mode)
+    got = m7.head_forward(ops.to_device(g["pre"]), ops.to_device(g["quals"])).cpu().numpy()
+    assert got.shape == g["logits"].shape and np.isfinite(got).all()
+    err = np.abs(got - g["logits"]).max()
+    assert err <= ATOL, f"HIP head vs reference head.py: max |dlogit| = {err:.3e} ({model.gemm_mode})"
+    m7.close()
 
 
 def test_forward_deterministic_and_batch_invariant(env):
@@ -325,3 +330,83 @@ def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
         outs[gather] = (model.forward(d_ids, d_q).cpu().numpy(), model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy())
     assert np.array_equal(outs[True][0], outs[False][0])
     assert np.array_equal(outs[True][1], outs[False][1])
+
+
+def _robustness_cases():
+    from deepchopper_amd.weights import BB, HD
+
+    def outlier(key):
+        def f(sd, rng):
+            w = sd[key].copy()
+            flat = w.reshape(-1)
+            flat[int(rng.integers(0, flat.size))] *= np.float32(1.0e3)
+            sd[key] = w
+        return f
+
+    def gamma_decades(sd, rng):
+        for k in list(sd):
+            if k.endswith(("norm1.weight", "norm2.weight", "ln_f.weight")):
+                sd[k] = np.exp(rng.uniform(np.log(1e-2), np.log(1e2), sd[k].shape)).astype(np.float32) * np.sign(sd[k])
+
+    def tiny_out_proj_input(sd, rng):
+        for i in range(4):  # u scaled by 0.05 -> the gated long-convolution output y ~ u^3 ~ 1e-4
+            for n in ("in_proj.weight", "in_proj.bias"):
+                sd[BB + f"layers.{i}.mixer.{n}"] = sd[BB + f"layers.{i}.mixer.{n}"] * np.float32(0.05)
+
+    def big_embeddings(sd, rng):
+        sd[BB + "embeddings.word_embeddings.weight"] = sd[BB + "embeddings.word_embeddings.weight"] * np.float32(50.0)
+
+    cases = {f"outlier:{k.split('.', 1)[1] if k.startswith(BB) else k}": outlier(k) for k in (
+        BB + "layers.1.mixer.in_proj.weight", BB + "layers.1.mixer.out_proj.weight", BB + "layers.2.mlp.fc1.weight",
+        BB + "layers.2.mlp.fc2.weight", HD + "linear1.weight", HD + "linear2.weight")}
+    cases.update({"layernorm_gamma_1e-2..1e2": gamma_decades, "out_proj_input_1e-4": tiny_out_proj_input,
+                  "embeddings_x50": big_embeddings})
+    return cases
+
+
+@pytest.mark.parametrize("case", list(_robustness_cases()))
+def test_precision_robustness_vs_float64(hip_lib, case):
+    """the default arithmetic (fp16x3: 22-bit products, per-tensor power-of-two weight scale) on
+    weights a trained checkpoint may have -- one outlier x1e3 in a GEMM tensor (pushes the other weights' low parts
+    towards fp16 subnormals), LayerNorm gains over four decades (folded into the next projection), tiny out_proj
+    inputs (the `l` term vanishes), large embeddings.  Against a float64 evaluation of the oracle the fp16x3 error
+    must stay within 4x the fp32-MFMA mode's (or the torch-fp32 oracle's own), or the range guard must fire and the
+    bf16x6 fallback must meet that bound."""
+    import torch
+
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = dict(synthetic_state_dict(13))
+    _robustness_cases()[case](sd, np.random.default_rng(99))
+    rng = np.random.default_rng(5)
+    ids, q = _inputs(rng, 3, 333)
+    ref64 = fr.forward(sd, ids, q, dtype=torch.float64).numpy()
+    ref32 = fr.forward(sd, ids, q).numpy()
+    scale = max(1.0, float(np.abs(ref64).max()))
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    errs = {"oracle_f32": float(np.abs(ref32 - ref64).max())}
+    model.set_gemm_mode("f32")
+    errs["f32"] = float(np.abs(model.forward(d_ids, d_q).cpu().numpy() - ref64).max())
+    model.set_gemm_mode("bf16x6")
+    errs["bf16x6"] = float(np.abs(model.forward(d_ids, d_q).cpu().numpy() - ref64).max())
+    model.set_gemm_mode("fp16x3")
+    counter = torch.zeros(1, dtype=torch.int32, device=d_ids.device)
+    model.set_overflow_target(counter)
+    raw = model.forward(d_ids, d_q).cpu().numpy()
+    model.set_overflow_target(None)
+    guard = int(counter.item())
+    out = model.forward_checked(d_ids, d_q).cpu().numpy()
+    errs["fp16x3"] = float(np.abs(out - ref64).max())
+    errs["fp16x3_unchecked"] = float(np.abs(raw - ref64).max()) if np.isfinite(raw).all() else float("inf")
+    print(case, "scale", scale, "guard", guard, {k: f"{v:.3e}" for k, v in errs.items()})
+    yard = max(errs["f32"], errs["oracle_f32"])
+    assert np.isfinite(out).all()
+    assert errs["bf16x6"] <= 4 * yard + 1e-6 * scale, errs
+    assert errs["fp16x3"] <= 4 * yard + 1e-6 * scale, errs   # after the guard's fallback, if it fired
+    if guard == 0:
+        assert errs["fp16x3_unchecked"] == errs["fp16x3"]
+    assert errs["fp16x3"] <= 1e-3 * scale                      # north_star's tolerance, with margin to spare
+    model.close()

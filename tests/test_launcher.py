@@ -1,0 +1,109 @@
+"""CPU tests of the command's own per-GPU launcher (deepchopper_amd/launcher.py): worker environment, the
+single-inflater chunk feed for plain gzip (parent parses once, workers receive their chunks over pipes), the
+parent's merge of per-rank BGZF parts, failure propagation.  The workers here are plain CPU scripts."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from deepchopper_amd import launcher, synth
+from deepchopper_amd.chop import merge_bgzf_parts
+from deepchopper_amd.fastq import BgzfWriter, FastqReader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, zlib
+    sys.path.insert(0, %r)
+    from deepchopper_amd.launcher import PipeChunks
+    from deepchopper_amd.fastq import BgzfWriter
+    fd, part = int(sys.argv[1]), sys.argv[2]
+    n = 0
+    names = []
+    with BgzfWriter(part, threads=1) as w:
+        for c in PipeChunks(fd):
+            n += c.n
+            names += c.names()
+            w.write_chunk(c) if c._name_len is None else None
+    print("noise before the report")
+    print(json.dumps({"rank": int(os.environ["RANK"]), "world": int(os.environ["WORLD_SIZE"]), "reads": n,
+                      "first": names[0] if names else None, "local_rank": os.environ["LOCAL_RANK"],
+                      "master": os.environ["MASTER_ADDR"]}))
+""" % ROOT)
+
+
+def test_chunk_frames_round_trip(tmp_path):
+    seqs, quals, ids = synth.synth_reads_mixed(23, 50, 400, seed=3)
+    fq = tmp_path / "a.fq"
+    fq.write_bytes(synth.fastq_text([i.encode() + b" ch=%d" % k for k, i in enumerate(ids)], seqs, quals))
+    for full in (False, True):
+        frames = tmp_path / f"frames{int(full)}.bin"
+        with FastqReader(str(fq), full_header=full) as rd, open(frames, "wb") as fh:
+            want = []
+            for c in rd.chunks(5, 3000):
+                launcher.write_chunk(fh, c)
+                want.append((c.n, c.seq.tobytes(), c.qual.tobytes(), c.offsets.tolist(), c._names.tobytes(), c.names(),
+                             None if c._name_len is None else c._name_len.tolist()))
+        got = []
+        with open(frames, "rb") as fh:
+            while True:
+                c = launcher.read_chunk(fh)
+                if c is None:
+                    break
+                got.append((c.n, c.seq.tobytes(), c.qual.tobytes(), c.offsets.tolist(), c._names.tobytes(), c.names(),
+                            None if c._name_len is None else c._name_len.tolist()))
+        assert got == want and sum(g[0] for g in got) == 23
+        assert [n for g in got for n in g[5]] == ids
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_single_inflater_feeds_every_worker_and_parts_merge(tmp_path, world):
+    seqs, quals, ids = synth.synth_reads_mixed(61, 60, 900, seed=9)
+    fq = tmp_path / "reads.fastq.gz"
+    text = synth.to_fastq(seqs, quals, ids)
+    with gzip.open(fq, "wb") as fh:
+        fh.write(text)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    feeder = launcher.ChunkFeeder(str(fq), world, max_reads=4, max_bases=5000)
+    port = launcher.free_port()
+    procs, parts = [], []
+    for r in range(world):
+        parts.append(str(tmp_path / f"part{r}.gz"))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(feeder.read_fds[r]), parts[-1]],
+                                      env=launcher.rank_env(r, world, port, share_gpu=(world == 3)),
+                                      pass_fds=(feeder.read_fds[r],), stdout=subprocess.PIPE, text=True))
+    feeder.start()
+    outs = launcher.wait_ranks(procs, timeout=120)
+    feeder.join()
+    reports = [launcher.last_json_line(o) for o in outs]
+    assert [r["rank"] for r in reports] == list(range(world)) and all(r["world"] == world for r in reports)
+    assert sum(r["reads"] for r in reports) == 61 == feeder.n_reads
+    assert all(r["reads"] > 0 for r in reports) and reports[0]["first"] == ids[0]
+    assert [r["local_rank"] for r in reports] == (["0"] * 3 if world == 3 else ["0", "1"])
+    assert all(r["master"] == "127.0.0.1" for r in reports)
+    final = str(tmp_path / "merged.fq.gz")
+    merge_bgzf_parts(parts, final)
+    assert not any(os.path.exists(p) for p in parts)
+    merged = gzip.open(final, "rb").read()
+    # chunks were dealt round-robin: the merged file holds every record exactly once, rank by rank
+    recs = sorted(merged.split(b"@read_")[1:])
+    assert recs == sorted(text.split(b"@read_")[1:])
+    with FastqReader(final) as rd:  # and our own reader (BGZF with EOF blocks in the middle) reads it all
+        assert sum(c.n for c in rd.chunks()) == 61
+
+
+def test_failed_worker_is_reported(tmp_path):
+    ok = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(30)"], stdout=subprocess.PIPE, text=True)
+    bad = subprocess.Popen([sys.executable, "-c", "import sys; print('{}'); sys.exit(3)"], stdout=subprocess.PIPE, text=True)
+    with pytest.raises(RuntimeError, match="rank 1 exited with status 3"):
+        launcher.wait_ranks([ok, bad], timeout=60)
+    assert ok.poll() is not None  # the survivor was terminated, not left behind
+    with pytest.raises(ValueError):
+        launcher.last_json_line("no report here")
+    assert launcher.last_json_line('x\n{"a": 1}\n') == {"a": 1}

@@ -1,13 +1,25 @@
-"""File-to-intervals throughput of the streaming predict path (FASTQ on disk -> native reader -> H2D ->
-tokenise/forward/smooth -> D2H labels + intervals), next to the parse-only rate of the host reader.
-This is the PCIe- and parse-inclusive figure DESIGN.md quotes beside bench.py's HBM-resident `value`.
+"""End-to-end rates either side of the hot path, on files.
 
-    python tools/bench_e2e.py --reads 100000 --bp 1000 --container plain|gzip|bgzf
+* default: file-to-intervals throughput of the streaming predict path (FASTQ on disk -> native reader -> H2D ->
+  tokenise/forward/smooth -> D2H labels + intervals) on fixed-length reads, next to the parse-only rate of the host
+  reader -- the PCIe- and parse-inclusive figure DESIGN.md quotes beside bench.py's HBM-resident `value`.
+
+      python tools/bench_e2e.py --reads 100000 --bp 1000 --container plain|gzip|bgzf
+
+* `--chop`: BASELINE config 5's flow -- a nanopore-like `.fastq.gz` (log-normal lengths, ONT-style headers, adapters
+  planted as N runs, `weights.token_gated_state_dict` so that predict really finds them) through the fused
+  `predict -> chop` (no `.pt` files) into a chopped BGZF FASTQ; reports reads/s, bases/s, peak host RSS and what
+  became of the reads.  `--gpus N` runs the command's own launcher (one worker per GPU; DC_SHARE_GPU=1 rehearses
+  it on one GPU), where plain gzip goes through the parent's single inflater.
+
+      python tools/bench_e2e.py --chop --reads 1000000 --container gzip [--gpus 2]
 """
 import argparse
 import gzip
 import json
 import os
+import resource
+import subprocess
 import sys
 import tempfile
 import time
@@ -17,24 +29,125 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
+def _opener(container, path):
+    from deepchopper_amd.fastq import BgzfWriter
+
+    return {"plain": lambda: open(path, "wb"), "gzip": lambda: gzip.open(path, "wb", compresslevel=1),
+            "bgzf": lambda: BgzfWriter(path, threads=8, level=1)}[container]()
+
+
+def _count_output(path):
+    """Records of the chopped file by kind (terminal / internal chop, passed through)."""
+    from deepchopper_amd.fastq import FastqReader
+
+    n = n_t = n_i = bases = 0
+    with FastqReader(path) as rd:
+        for c in rd.chunks(65536, 256 << 20):
+            raw, o = c._names.tobytes(), c._name_offsets
+            n += c.n
+            bases += int(c.offsets[c.n])
+            for k in range(c.n):
+                tail = raw[o[k + 1] - 2: o[k + 1]]
+                n_t += tail == b"|T"
+                n_i += tail == b"|I"
+    return {"records": n, "terminal_chops": int(n_t), "internal_chop_segments": int(n_i), "passed_through": int(n - n_t - n_i),
+            "bases_out": bases}
+
+
+def chop_bench(args):
+    from deepchopper_amd import synth
+    from deepchopper_amd.weights import save_state_dict, token_gated_state_dict
+
+    tmp = tempfile.mkdtemp(prefix="dc_c5_")
+    path = os.path.join(tmp, "hct116_like.fastq.gz" if args.container != "plain" else "hct116_like.fastq")
+    t0 = time.time()
+    n_bases = 0
+    with _opener(args.container, path) as fh:
+        for b0 in range(0, args.reads, 50_000):
+            n = min(50_000, args.reads - b0)
+            h, s, q = synth.synth_nanopore_like(n, seed=42 + b0, start_index=b0)
+            n_bases += sum(len(x) for x in s)
+            fh.write(synth.fastq_text(h, s, q))
+    gen_s = time.time() - t0
+    ckpt = os.path.join(tmp, "ckpt")
+    save_state_dict(token_gated_state_dict(0), os.path.join(ckpt, "model.safetensors"))
+    out = {"flow": "fused predict -> chop (no .pt)", "container": args.container, "reads": args.reads, "bases": n_bases,
+           "mean_len": round(n_bases / args.reads, 1), "file_MB": round(os.path.getsize(path) / 1e6, 1), "gen_s": round(gen_s, 1),
+           "gpus": args.gpus, "bgzf_threads": args.threads}
+    os.chdir(tmp)
+    if args.gpus == 1 and not args.cli:
+        import torch
+
+        from deepchopper_amd.chop import predict_chop
+        from deepchopper_amd.model import DeepChopper
+        from deepchopper_amd.predict import PredictPipeline
+
+        torch.cuda.set_device(0)
+        pipe = PredictPipeline(DeepChopper.from_pretrained(ckpt))
+        warm = os.path.join(tmp, "warm.fastq")
+        h, s, q = synth.synth_nanopore_like(20_000, seed=7)
+        with open(warm, "wb") as fh:
+            fh.write(synth.fastq_text(h, s, q))
+        final, _, _ = predict_chop(warm, pipe, threads=args.threads, max_reads=args.max_reads, max_tokens=args.max_tokens)
+        os.remove(final)
+        os.remove(warm)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        final, n_reads, n_out = predict_chop(path, pipe, threads=args.threads, max_reads=args.max_reads, max_tokens=args.max_tokens)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    else:
+        cmd = [sys.executable, "-m", "deepchopper_amd.cli", "predict", path, "-g", str(args.gpus), "--chop", "-m", ckpt,
+               "-t", str(args.threads), "--max-reads", str(args.max_reads), "--max-tokens", str(args.max_tokens), "-b", str(12 * args.gpus)]
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        t0 = time.time()
+        proc = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        dt = time.time() - t0
+        if proc.returncode != 0:
+            raise SystemExit(proc.stderr[-3000:])
+        final = proc.stdout.strip().splitlines()[-1]
+        import re
+
+        n_reads = int(re.search(r"\.(\d+)pd\.", os.path.basename(final)).group(1))
+        rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+        out["note"] = "wall time of the whole command (interpreter + model load + first-batch warm-up included)"
+    out.update({"seconds": round(dt, 2), "reads_per_s": round(n_reads / dt, 1), "Mbases_per_s": round(n_bases / dt / 1e6, 2),
+                "peak_host_rss_MB": round(rss / 1024, 1), "output": os.path.basename(final),
+                "output_MB": round(os.path.getsize(final) / 1e6, 1)})
+    if not args.no_count:
+        out.update(_count_output(final))
+    print(json.dumps(out))
+    os.remove(final)
+    os.remove(path)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--bp", type=int, default=1000)
     ap.add_argument("--container", default="plain", choices=["plain", "gzip", "bgzf"])
     ap.add_argument("--max-reads", type=int, default=2048)
+    ap.add_argument("--max-tokens", type=int, default=2_000_000)
     ap.add_argument("--parse-only", action="store_true")
+    ap.add_argument("--chop", action="store_true", help="config-5 flow: nanopore-like reads -> fused predict -> chop -> BGZF")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cli", action="store_true", help="--chop through the command line even on one GPU")
+    ap.add_argument("--threads", type=int, default=4, help="BGZF compression workers of the chop output")
+    ap.add_argument("--no-count", action="store_true")
     args = ap.parse_args()
+    if args.chop:
+        if args.max_reads == 2048:
+            args.max_reads = 8192
+        return chop_bench(args)
     from deepchopper_amd import synth
-    from deepchopper_amd.fastq import BgzfWriter, FastqReader
+    from deepchopper_amd.fastq import FastqReader
 
     tmp = tempfile.mkdtemp(prefix="dc_e2e_")
     path = os.path.join(tmp, "reads.fq")
     t0 = time.time()
     block = 10_000
-    opener = {"plain": lambda: open(path, "wb"), "gzip": lambda: gzip.open(path, "wb", compresslevel=1),
-              "bgzf": lambda: BgzfWriter(path, threads=8, level=1)}[args.container]
-    with opener() as fh:
+    with _opener(args.container, path) as fh:
         for b0 in range(0, args.reads, block):
             n = min(block, args.reads - b0)
             seq, qual, ids = synth.synth_reads_fixed(n, args.bp, seed=42 + b0, start_index=b0)
