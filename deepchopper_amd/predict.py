@@ -188,7 +188,7 @@ class PredictPipeline:
 
     # ---- streaming: FASTQ chunks -> labels / intervals, host I/O overlapped with GPU work ---------------
     def predict_stream(self, chunks, *, prefetch: int = 2, want_labels: bool = True, reference_padding: bool = False,
-                       ids_i64: bool = False, borrow: bool = False, want_names: bool = True):
+                       ids_i64: bool = False, borrow: bool = False, want_names: bool = True, serialize: bool = False):
         """`chunks`: an iterator of fastq.FastqChunk (e.g. `FastqReader.chunks(max_reads, max_tokens)`).
         Yields one result dict per chunk, in input order: `names`, `lengths`, packed per-base labels
         (`pred`, `smooth` + `offsets`; only with want_labels), `intervals` / `n_intervals`, `keep` / `n_keep`,
@@ -201,6 +201,9 @@ class PredictPipeline:
         memory; the host hands out batch k-2... i.e. the only wait is for a batch's own copy event.
         The fp16x3 range guard is attributed per batch: every batch has its own device counter, read back with
         its results, so a batch launched while an earlier one is collected cannot lose (or lend) its overflow.
+
+        serialize=True (A/B measurements only): wait for every batch before the next one is launched -- the
+        behaviour of a pipeline whose per-batch copies block the host.
 
         borrow=True: the yielded host arrays are views into pinned staging that is reused once the consumer
         asks for the next result (the fused chop driver consumes them at once); otherwise they are copies."""
@@ -219,6 +222,7 @@ class PredictPipeline:
 
         def produce():
             try:
+                torch.cuda.set_device(dev)  # pinned allocations of this thread belong to the pipeline's device
                 for c in chunks:
                     slot = None
                     while slot is None and not stop.is_set():
@@ -328,6 +332,8 @@ class PredictPipeline:
                 if isinstance(item, BaseException):
                     raise item
                 launched = launch(item) if item is not None else None
+                if serialize and launched is not None:
+                    launched["copied"].synchronize()
                 if pending is not None:
                     yield collect(pending)
                     free.put(pending["slot"])  # the consumer is done with the borrowed views

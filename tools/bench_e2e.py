@@ -122,6 +122,44 @@ def chop_bench(args):
     os.remove(path)
 
 
+def ref_batch_bench(args):
+    """`deepchopper predict -b 12` shape: tiny left-padded batches, where per-batch host waits dominate.  Same
+    stream twice: pipelined (non-blocking pinned copies, results on a copy stream) and serialised (every batch
+    waited for before the next launch, i.e. what blocking per-batch copies cost)."""
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+
+    tmp = tempfile.mkdtemp(prefix="dc_ref_")
+    path = os.path.join(tmp, "reads.fq")
+    with open(path, "wb") as fh:
+        for b0 in range(0, args.reads, 10_000):
+            n = min(10_000, args.reads - b0)
+            seq, qual, ids = synth.synth_reads_fixed(n, args.bp, seed=42 + b0, start_index=b0)
+            fh.write(synth.to_fastq(seq, qual, ids))
+    torch.cuda.set_device(0)
+    pipe = PredictPipeline(DeepChopper.synthetic(seed=42))
+    out = {"mode": f"reference batches of {args.ref_batch} reads (left-padded, int64 ids, labels + intervals to the host)",
+           "reads": args.reads, "bp": args.bp}
+    for name, ser in (("warmup", False), ("pipelined", False), ("serialised", True)):
+        t0 = time.time()
+        n = 0
+        with FastqReader(path) as rd:
+            for res in pipe.predict_stream(rd.chunks(args.ref_batch, 1 << 26), reference_padding=True, ids_i64=True, serialize=ser):
+                n += len(res["names"])
+                if name == "warmup" and n >= 50 * args.ref_batch:
+                    break
+        torch.cuda.synchronize()
+        if name != "warmup":
+            out[name + "_reads_per_s"] = round(n / (time.time() - t0), 1)
+    print(json.dumps(out))
+    os.remove(path)
+    os.rmdir(tmp)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=100_000)
@@ -135,7 +173,11 @@ def main():
     ap.add_argument("--cli", action="store_true", help="--chop through the command line even on one GPU")
     ap.add_argument("--threads", type=int, default=4, help="BGZF compression workers of the chop output")
     ap.add_argument("--no-count", action="store_true")
+    ap.add_argument("--ref-batch", type=int, default=0, help="reference-compatible mode: batches of this many reads "
+                    "(the reference's -b 12), left-padded, int64 ids; reports reads/s pipelined and serialised")
     args = ap.parse_args()
+    if args.ref_batch:
+        return ref_batch_bench(args)
     if args.chop:
         if args.max_reads == 2048:
             args.max_reads = 8192
