@@ -1304,10 +1304,37 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   }
 }
 
+#include "mlp4_kernel.inc"
+
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
   DC_REQUIRE(g.K == M_D && g.N % M_HC == 0 && g.N <= 1024 && g.Tp % M_BT == 0, "fused MLP: d_model 256, d_inner <= 1024");
   DC_REQUIRE(g.X == g.R && g.mean && g.rstd && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
+  if (g.Wp3)
+    DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && g.N3 <= 1024 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
+               "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
+  // default: the 8-wave form (256 tokens per workgroup, X tile streamed once per hidden chunk).  DC_MLP_WAVES=4
+  // selects the 4-wave form that keeps the token tile in registers and reads X once: it moves 10x less fabric
+  // traffic but 15 % more LDS-DMA bytes per token (weights per 128 instead of 256 tokens: 21.5 vs 18.7 KB) and,
+  // at one wave per SIMD, cannot hide their issue cost behind a partner wave -- measured 10.4-10.9 ms against
+  // 9.0-9.1 ms per launch (profiles/r02_mlp4_*).
+  static const bool four = getenv("DC_MLP_WAVES") && atoi(getenv("DC_MLP_WAVES")) == 4;
+  if (four) {
+    const dim3 grid4((unsigned)(g.Tp / Q_BT)), block4(64 * Q_NW);
+    if (g.Wp3 && g.epi3 == EPI_BIAS) {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp4_kernel<true, EPI_BIAS>), grid4, block4, 0, st, g);
+      else hipLaunchKernelGGL((mlp4_kernel<false, EPI_BIAS>), grid4, block4, 0, st, g);
+    } else if (g.Wp3) {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp4_kernel<true, EPI_BIAS_RELU_Q>), grid4, block4, 0, st, g);
+      else hipLaunchKernelGGL((mlp4_kernel<false, EPI_BIAS_RELU_Q>), grid4, block4, 0, st, g);
+    } else if (g.gelu_tanh) {
+      hipLaunchKernelGGL((mlp4_kernel<true, -1>), grid4, block4, 0, st, g);
+    } else {
+      hipLaunchKernelGGL((mlp4_kernel<false, -1>), grid4, block4, 0, st, g);
+    }
+    DC_LAUNCH_CHECK();
+    return DC_OK;
+  }
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
   if (g.Wp3) {
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
