@@ -78,6 +78,7 @@ struct HyenaArgs {
   const int32_t* grp_P;      // [n_groups] max 32-token blocks over the group's reads
   const int32_t* toff;       // [n_reads] first token column
   const int32_t* nblk;       // [n_reads] 32-token blocks
+  const int32_t* ntok;       // [n_reads] tokens (FFT long convolution: exact read length)
   int64_t Tp;
   int D;
   int CH;              // channels per workgroup (1, 2 or 4)
@@ -106,6 +107,13 @@ int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
+// O(L log L) long convolution for long reads (hyena_fft.hip): 2^logm complex points per (read, channel), logm 11..14
+int fft_twiddle_count();                           // float2 entries of the twiddle table
+int launch_fft_twiddles(hipStream_t st, float* tw);
+int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t kf_stride, int kf_taps, int D,
+                            const float* tw, float* spec);  // spec: [D][2^logm + 1] float2
+int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,
+                     const float* spec);
 int hyena3_units(int kf_taps);  // 16-byte units per (plane, shift) copy of the bf16 filter planes
 int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
                          unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale);

@@ -36,6 +36,7 @@ struct LayerDev {
   unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
   unsigned short* kfq = nullptr;  // fp16 planes (2) of the per-channel scaled filter
   float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
+  float* kspec[4] = {nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 11..14
 };
 
 struct ProfEvent {
@@ -62,6 +63,13 @@ struct dc_model {
   int mlp_fusion = 1;  // fp16x3: fc1 -> GELU -> fc2 in one kernel (dc_model_set_mlp_fusion)
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
+  float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
+  bool kspec_valid[4] = {false, false, false, false};  // spectra match the materialised filters
+  int fft_min_tokens = 3072;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
+  // FFT buckets of the cached geometry: read lists by transform size
+  int32_t* d_fft_reads = nullptr;
+  int fft_count[4] = {0, 0, 0, 0}, fft_offset[4] = {0, 0, 0, 0};
+  int max_P_mfma = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
 
@@ -303,6 +311,27 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
     if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp, L.kfq, L.kscale, L.kinv))) return rc;
   }
   m->kf_taps = taps;
+  for (bool& v : m->kspec_valid) v = false;
+  return DC_OK;
+}
+
+// Filter spectra of every layer for transforms of 2^logm complex points (built once per materialised filter).
+int ensure_fft_spectra(dc_model* m, hipStream_t st, int logm) {
+  const int b = logm - 11;
+  DC_REQUIRE(b >= 0 && b < 4, "FFT size out of range");
+  if (!m->fft_tw) {
+    DC_HIP_CHECK(hipMalloc((void**)&m->fft_tw, (size_t)fft_twiddle_count() * 2 * sizeof(float)));
+    int rc = launch_fft_twiddles(st, m->fft_tw);
+    if (rc) return rc;
+  }
+  if (m->kspec_valid[b]) return DC_OK;
+  const size_t bytes = (size_t)m->cfg.d_model * (((size_t)1 << logm) + 1) * 2 * sizeof(float);
+  for (auto& L : m->layers) {
+    if (!L.kspec[b]) DC_HIP_CHECK(hipMalloc((void**)&L.kspec[b], bytes));
+    int rc = launch_hyena_fft_filter(st, logm, L.kf, m->kf_taps, (int)m->kf_taps, m->cfg.d_model, m->fft_tw, L.kspec[b]);
+    if (rc) return rc;
+  }
+  m->kspec_valid[b] = true;
   return DC_OK;
 }
 
@@ -390,10 +419,11 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
                    const int32_t* h_ntok) {
   // geometry key
   std::vector<int32_t> key;
-  key.reserve(2 * (size_t)n_reads + 3);
+  key.reserve(2 * (size_t)n_reads + 4);
   key.push_back(n_reads);
   key.push_back((int32_t)(row_stride & 0x7fffffff));
   key.push_back((int32_t)(row_stride >> 31));
+  key.push_back(m->fft_min_tokens);
   key.insert(key.end(), h_first, h_first + n_reads);
   key.insert(key.end(), h_ntok, h_ntok + n_reads);
   if (key == m->h_geom && m->Tp > 0) return DC_OK;
@@ -416,15 +446,36 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
   const int64_t n_tb = Tp / 32;
 
-  // groups of 32 reads of similar length (longest first) for the long-convolution kernel
+  // Long reads (more than fft_min_tokens tokens, up to 2^14) take the FFT long convolution, bucketed by transform
+  // size; the others form groups of 32 reads of similar length (longest first) for the block-Toeplitz kernel.
   std::vector<int32_t> order(n_reads);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
-  const int n_groups = (n_reads + 31) / 32;
-  std::vector<int32_t> grp_reads((size_t)n_groups * 32, -1), grp_P(n_groups, 0);
+  std::vector<int32_t> fft_lists[4], mfma_order;
   for (int j = 0; j < n_reads; ++j) {
-    grp_reads[j] = order[j];
-    grp_P[j / 32] = std::max(grp_P[j / 32], nblk[order[j]]);
+    const int r = order[j], nt = h_ntok[r];
+    if (nt > m->fft_min_tokens && nt <= (1 << 14)) {
+      int logm = 11;
+      while ((1 << logm) < nt) ++logm;
+      fft_lists[logm - 11].push_back(r);
+    } else {
+      mfma_order.push_back(r);
+    }
+  }
+  const int n_mfma = (int)mfma_order.size();
+  const int n_groups = (n_mfma + 31) / 32;
+  std::vector<int32_t> grp_reads((size_t)std::max(n_groups, 1) * 32, -1), grp_P(std::max(n_groups, 1), 0);
+  int maxP_mfma = 0;
+  for (int j = 0; j < n_mfma; ++j) {
+    grp_reads[j] = mfma_order[j];
+    grp_P[j / 32] = std::max(grp_P[j / 32], nblk[mfma_order[j]]);
+    maxP_mfma = std::max(maxP_mfma, nblk[mfma_order[j]]);
+  }
+  std::vector<int32_t> fft_reads;
+  for (int b = 0; b < 4; ++b) {
+    m->fft_offset[b] = (int)fft_reads.size();
+    m->fft_count[b] = (int)fft_lists[b].size();
+    fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
   }
   std::vector<int32_t> blk_read(n_tb, -1);
   std::vector<int64_t> src_base(n_reads);
@@ -442,7 +493,8 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   size_t o_nblk = al8(o_ntok + sizeof(int32_t) * n_reads);
   size_t o_gr = al8(o_nblk + sizeof(int32_t) * n_reads);
   size_t o_gp = al8(o_gr + sizeof(int32_t) * grp_reads.size());
-  size_t total = al8(o_gp + sizeof(int32_t) * n_groups);
+  size_t o_fr = al8(o_gp + sizeof(int32_t) * grp_P.size());
+  size_t total = al8(o_fr + sizeof(int32_t) * std::max<size_t>(fft_reads.size(), 1));
 
   if (m->staging_pending) {
     DC_HIP_CHECK(hipEventSynchronize(m->staging_done));
@@ -466,7 +518,8 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   memcpy(hp + o_ntok, h_ntok, sizeof(int32_t) * n_reads);
   memcpy(hp + o_nblk, nblk.data(), sizeof(int32_t) * n_reads);
   memcpy(hp + o_gr, grp_reads.data(), sizeof(int32_t) * grp_reads.size());
-  memcpy(hp + o_gp, grp_P.data(), sizeof(int32_t) * n_groups);
+  memcpy(hp + o_gp, grp_P.data(), sizeof(int32_t) * grp_P.size());
+  if (!fft_reads.empty()) memcpy(hp + o_fr, fft_reads.data(), sizeof(int32_t) * fft_reads.size());
   DC_HIP_CHECK(hipMemcpyAsync(m->idx.p, m->pinned, total, hipMemcpyHostToDevice, st));
   DC_HIP_CHECK(hipEventRecord(m->staging_done, st));
   m->staging_pending = true;
@@ -479,6 +532,8 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   m->d_nblk = (int32_t*)(dp + o_nblk);
   m->d_grp_reads = (int32_t*)(dp + o_gr);
   m->d_grp_P = (int32_t*)(dp + o_gp);
+  m->d_fft_reads = (int32_t*)(dp + o_fr);
+  m->max_P_mfma = maxP_mfma;
   m->Tp = Tp;
   m->n_groups = n_groups;
   m->max_P = maxP;
@@ -538,6 +593,8 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
   if ((rc = ensure_workspace(m, m->Tp))) return rc;
   if ((rc = ensure_filters(m, st, (int64_t)m->max_P * 32))) return rc;
+  for (int b = 0; b < 4; ++b)
+    if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 11 + b))) return rc;
 
   const int D = c.d_model, DI = c.d_inner, H = c.head_hidden;
   float* x = (float*)m->x.p;
@@ -571,7 +628,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
     if (rc) return rc;
   }
   // channels per workgroup of the long-convolution kernel: keep all four waves busy on short reads
-  const int nchunk_min = (m->max_P + 3) / 4;
+  const int nchunk_min = (std::max(m->max_P_mfma, 1) + 3) / 4;
   const int CH = nchunk_min >= 7 ? 1 : (nchunk_min >= 3 ? 2 : 4);
 
   static const bool no_mlp_chain = getenv("DC_NO_MLP_CHAIN") != nullptr;  // A/B switch
@@ -606,6 +663,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.grp_P = m->d_grp_P;
       a.toff = m->d_toff;
       a.nblk = m->d_nblk;
+      a.ntok = m->d_ntok;
       a.Tp = Tp;
       a.D = D;
       a.CH = CH;
@@ -625,9 +683,19 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
       static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
       const int hy = hy_env ? hy_env : (m->gemm_mode >= 1 ? 3 : 2);
-      rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P)
-                   : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P) : launch_hyena3(st, a, m->n_groups, m->max_P);
-      if (rc) return rc;
+      if (m->n_groups > 0) {
+        rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P_mfma)
+                     : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P_mfma)
+                               : launch_hyena3(st, a, m->n_groups, m->max_P_mfma);
+        if (rc) return rc;
+      }
+      // long reads: O(L log L) FFT convolution, one launch per transform size present in the batch
+      for (int b = 0; b < 4; ++b) {
+        if (m->fft_count[b] == 0) continue;
+        ProfScope pf(m, st, "hyena_fft");
+        if ((rc = launch_hyena_fft(st, a, 11 + b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
+          return rc;
+      }
     }
     if (sums && (rc = zero_stats())) return rc;
     if ((rc = run_gemm(m, st, "gemm_outproj", WRef{L.Wt_out, L.Wp_out, L.Wq_out, L.is_out}, y, x, L.b_out, x, nullptr, false,
@@ -724,6 +792,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   m->cfg = *cfg;
   if (const char* e = getenv("DC_GEMM_MODE"))
     m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : ((strcmp(e, "fp16x3") == 0 || strcmp(e, "2") == 0) ? 2 : 1);
+  if (const char* e = getenv("DC_FFT_MIN")) m->fft_min_tokens = std::max(1024, atoi(e));
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
   {
@@ -850,7 +919,10 @@ extern "C" void dc_model_free(dc_model* m) {
     if (L.kfq) (void)hipFree(L.kfq);
     if (L.kscale) (void)hipFree(L.kscale);
     if (L.kinv) (void)hipFree(L.kinv);
+    for (float* p : L.kspec)
+      if (p) (void)hipFree(p);
   }
+  if (m->fft_tw) (void)hipFree(m->fft_tw);
   for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
     if (b->p) (void)hipFree(b->p);
   if (m->pinned) (void)hipHostFree(m->pinned);
@@ -941,6 +1013,13 @@ extern "C" int dc_model_overflow(dc_model* m, void* stream, int32_t* count) {
   DC_HIP_CHECK(hipStreamSynchronize(st));
   if (v) DC_HIP_CHECK(hipMemsetAsync(m->d_overflow, 0, sizeof(int), st));
   *count = v;
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_fft_threshold(dc_model* m, int32_t min_tokens) {
+  DC_REQUIRE(m, "null pointer");
+  DC_REQUIRE(min_tokens >= 1024, "the FFT long convolution takes reads of more than 1024 tokens (min_tokens >= 1024; a value above the model's context disables it)");
+  m->fft_min_tokens = min_tokens;
   return DC_OK;
 }
 

@@ -1,0 +1,407 @@
+// O(L log L) long convolution of the Hyena operator for long reads (the reference's `fftconv`,
+// HF-Hub remote code called at deepchopper/models/llm/hyena.py:34-41; restated in oracle/forward_ref.py:68-77).
+//
+// hyena3_kernel (forward_kernels.hip) evaluates the causal convolution as block-Toeplitz MFMA products: O(L^2) per
+// (read, channel), unbeatable at 1 kb but 43 % of the step on a 100 bp - 10 kb length mix.  Reads above a length
+// threshold take this path instead: one workgroup per (read, channel) runs
+//     z = shortconv(x1) * shortconv(v)                      (gated input, as the z tiles of hyena3)
+//     c[m] = z[2m] + i z[2m+1]                              (real sequence of 2M samples as M complex points)
+//     C = FFT_M(c)   ->  Z[k] (unpack)  ->  Y = Z * K       (K = spectrum of the layer's filter taps, built once)
+//     C'[k] (repack)  ->  c' = IFFT_M(C')                   (IFFT as conj . FFT . conj)
+//     y[t] = c'-sample[t] * shortconv(x0)[t],  t < L
+// entirely in LDS: M = 2^LOGM >= L complex points (2M real samples >= 2L: the circular convolution is the linear
+// one on [0, L)), fp32 throughout like the reference.  The FFT is a Stockham autosort radix-16 decimation in time
+// with the butterflies in registers (M / 16 threads, 16 points each per pass; the last pass has radix M / 16^k);
+// LDS points carry one pad slot per 16 (the first pass writes with a stride of 16 points: 17 slots = 34 dwords
+// is conflict free for ds_write_b64's 16-lane groups).  Twiddles come from one exact table (fp64 sincos once per
+// process) through four lookups w, w^2, w^4, w^8 and at most three products.
+// No rocFFT / hipFFT: the transform, its packing tricks and the gating are one kernel.
+#include "dc_common.h"
+#include "forward.h"
+
+namespace dc {
+
+namespace {
+
+constexpr int FFT_TW_N = 32768;  // twiddle table: exp(-2 pi i n / 32768)
+
+__global__ __launch_bounds__(256) void fft_twiddle_kernel(float2* __restrict__ tw) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= FFT_TW_N) return;
+  double s, c;
+  sincospi(-2.0 * (double)n / (double)FFT_TW_N, &s, &c);
+  tw[n] = make_float2((float)c, (float)s);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+constexpr int bitrev(int x, int bits) {
+  int r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+// exp(-2 pi i m / n) for the in-register butterflies (n <= 16): exact to fp32 rounding
+__device__ __forceinline__ float2 unit_root(int m, int n) {
+  // multiples of pi/8: cos / sin of k * 22.5 degrees
+  constexpr float C[5] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f};
+  const int k = (m * 16 / n) & 15;  // angle = -2 pi k / 16
+  const int q = k & 3, quad = k >> 2;
+  float c = C[q], s = C[4 - q];  // cos, sin of q * 22.5 deg
+  // rotate by quadrant: angle = -(quad * 90 + q * 22.5) degrees
+  float cr, sr;
+  switch (quad) {
+    case 0: cr = c; sr = -s; break;
+    case 1: cr = -s; sr = -c; break;
+    case 2: cr = -c; sr = s; break;
+    default: cr = s; sr = c; break;
+  }
+  return make_float2(cr, sr);
+}
+
+// In-register DFT of R points (decimation in frequency, radix 2): frequency f ends up at position bitrev(f).
+template <int R>
+__device__ __forceinline__ void dft_regs(float2 (&u)[R]) {
+#pragma unroll
+  for (int s = R / 2; s >= 1; s >>= 1) {
+#pragma unroll
+    for (int blk = 0; blk < R; blk += 2 * s) {
+#pragma unroll
+      for (int m = 0; m < s; ++m) {
+        const float2 a = u[blk + m], b = u[blk + m + s];
+        u[blk + m] = cadd(a, b);
+        const float2 d = csub(a, b);
+        u[blk + m + s] = m == 0 ? d : cmul(d, unit_root(m, 2 * s));
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int pad16(int idx) { return idx + (idx >> 4); }
+
+// One Stockham pass of radix R over the M points in LDS; p = product of the radices of the passes before it.
+// T = M / 16 threads; every thread owns 16 / R butterflies.  Loads of all threads precede all stores (two
+// barriers), so the pass runs in place.
+template <int LOGM, int R>
+__device__ __forceinline__ void fft_pass(float2* __restrict__ s, const float2* __restrict__ tw, int p, int tid) {
+  constexpr int M = 1 << LOGM, T = M / 16, NB = 16 / R, LOGR = ilog2(R);
+  float2 u[NB][R];
+  // twiddle lookups first: their L2 round trip overlaps the LDS reads and the barrier.
+  // w = exp(-2 pi i k / (p R)); w^t for t < R comes from w, w^2, w^4, w^8 and at most three products.
+  float2 w1[NB], w2[NB], w4[NB], w8[NB];
+  if (p > 1) {
+    const int step = FFT_TW_N / (p * R);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int k = (tid + b * T) & (p - 1);
+      w1[b] = tw[(k * step) & (FFT_TW_N - 1)];
+      if (R > 2) w2[b] = tw[(2 * k * step) & (FFT_TW_N - 1)];
+      if (R > 4) w4[b] = tw[(4 * k * step) & (FFT_TW_N - 1)];
+      if (R > 8) w8[b] = tw[(8 * k * step) & (FFT_TW_N - 1)];
+    }
+  }
+  // M / R and b T are multiples of 16, so the pad of a point is that of (tid) plus a constant: one base address,
+  // immediate offsets
+  const float2* sr = s + pad16(tid);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      constexpr int S = M / R;
+      u[b][t] = sr[(b * T + t * S) + ((b * T + t * S) >> 4)];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int i = tid + b * T;
+    const int k = i & (p - 1);
+    if (p > 1) {
+      float2 wp[16];
+      wp[1] = w1[b];
+      if (R > 2) wp[2] = w2[b];
+      if (R > 4) wp[4] = w4[b];
+      if (R > 8) wp[8] = w8[b];
+#pragma unroll
+      for (int t = 3; t < R; ++t) {
+        if ((t & (t - 1)) != 0) {  // not a power of two: highest set bit times the rest
+          const int hb = 1 << ilog2(t);
+          wp[t] = cmul(wp[hb], wp[t - hb]);
+        }
+      }
+#pragma unroll
+      for (int t = 1; t < R; ++t) u[b][t] = cmul(u[b][t], wp[t]);
+    }
+    dft_regs<R>(u[b]);
+    const int j = ((i - k) << LOGR) + k;
+    if (p >= 16) {  // p is a multiple of 16: constant offsets from one padded base
+      float2* sw = s + pad16(j);
+#pragma unroll
+      for (int t = 0; t < R; ++t) sw[bitrev(t, LOGR) * (p + (p >> 4))] = u[b][t];
+    } else {        // first pass (p = 1, j = R i with R = 16): slot 17 i + t
+      float2* sw = s + pad16(j);
+#pragma unroll
+      for (int t = 0; t < R; ++t) sw[bitrev(t, LOGR)] = u[b][t];
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOGM>
+__device__ __forceinline__ void fft_lds(float2* __restrict__ s, const float2* __restrict__ tw, int tid) {
+  // radices: 16 while they fit, then the rest (2, 4 or 8)
+  fft_pass<LOGM, 16>(s, tw, 1, tid);
+  fft_pass<LOGM, 16>(s, tw, 16, tid);
+  if constexpr (LOGM == 11) {
+    fft_pass<LOGM, 8>(s, tw, 256, tid);
+  } else {
+    fft_pass<LOGM, 16>(s, tw, 256, tid);
+    if constexpr (LOGM == 13) fft_pass<LOGM, 2>(s, tw, 4096, tid);
+    if constexpr (LOGM == 14) fft_pass<LOGM, 4>(s, tw, 4096, tid);
+  }
+}
+
+// Spectrum of a real sequence r[0 .. 2M) from C = FFT_M(r[2m] + i r[2m+1]), evaluated pairwise:
+//   Z[k] = E + W^k O,  Z[M-k] = conj(E - W^k O),  E = (C[k] + conj(C[M-k])) / 2,  O = -i (C[k] - conj(C[M-k])) / 2
+template <int LOGM>
+__device__ __forceinline__ void unpack_pair(float2 ck, float2 cmk, float2 wk, float2& zk, float2& zmk) {
+  const float2 b = cconj(cmk);
+  const float2 e = make_float2(0.5f * (ck.x + b.x), 0.5f * (ck.y + b.y));
+  const float2 d = make_float2(0.5f * (ck.x - b.x), 0.5f * (ck.y - b.y));
+  const float2 o = make_float2(d.y, -d.x);  // -i d
+  const float2 wo = cmul(wk, o);
+  zk = cadd(e, wo);
+  zmk = cconj(csub(e, wo));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter spectra: K[c][0 .. M] = rfft(kf[c][0 .. min(M, taps)), n = 2M)
+// ---------------------------------------------------------------------------------------------------
+template <int LOGM>
+__global__ __launch_bounds__((1 << LOGM) / 16) void hyena_fft_filter_kernel(const float* __restrict__ kf, int64_t kf_stride,
+                                                                              int kf_taps, const float2* __restrict__ tw,
+                                                                              float2* __restrict__ spec) {
+  constexpr int M = 1 << LOGM, T = M / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  float2* s = reinterpret_cast<float2*>(s_raw);
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float* k = kf + (int64_t)c * kf_stride;
+  for (int m = tid; m < M; m += T) {
+    const int t = 2 * m;
+    s[pad16(m)] = make_float2(t < kf_taps && t < M ? k[t] : 0.f, t + 1 < kf_taps && t + 1 < M ? k[t + 1] : 0.f);
+  }
+  __syncthreads();
+  fft_lds<LOGM>(s, tw, tid);
+  float2* out = spec + (int64_t)c * (M + 1);
+  for (int kk = tid; kk <= M / 2; kk += T) {
+    const float2 ck = s[pad16(kk)], cmk = s[pad16((M - kk) & (M - 1))];
+    float2 zk, zmk;
+    unpack_pair<LOGM>(ck, cmk, tw[kk * (FFT_TW_N / (2 * M))], zk, zmk);
+    if (kk == 0) {
+      out[0] = make_float2(ck.x + ck.y, 0.f);  // E[0] + O[0]
+      out[M] = make_float2(ck.x - ck.y, 0.f);  // Nyquist: E[0] - O[0]
+    } else {
+      out[kk] = zk;
+      out[M - kk] = zmk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the operator for one (read, channel)
+// ---------------------------------------------------------------------------------------------------
+template <int LOGM, bool TAB>
+__global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
+                                                                       const float2* __restrict__ tw,
+                                                                       const float2* __restrict__ spec) {
+  constexpr int M = 1 << LOGM, T = M / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  float2* s = reinterpret_cast<float2*>(s_raw);
+  float* s_tab = reinterpret_cast<float*>(s + (M + M / 16));  // TAB: x0 | x1 | v of this channel for ids 0..15, [16] = 0
+  const int r = reads[blockIdx.x], c = blockIdx.y, tid = threadIdx.x;
+  const int64_t toff = a.toff[r];
+  const int L = a.ntok[r];
+  const int D = a.D;
+  const float* ux0 = a.u + (int64_t)c * a.Tp + toff;
+  const float* ux1 = a.u + (int64_t)(D + c) * a.Tp + toff;
+  const float* uv = a.u + (int64_t)(2 * D + c) * a.Tp + toff;
+  const unsigned char* tok = TAB ? a.tok + toff : nullptr;
+  if (TAB) {
+    if (tid < 3 * 17) {
+      const int k3 = tid / 17, id = tid - 17 * k3;
+      s_tab[tid] = id < a.vocab && id < 16 ? a.tab[(int64_t)id * 3 * D + k3 * D + c] : 0.f;
+    }
+    __syncthreads();
+  }
+  // short causal filter (order 3, weight index 0 = oldest tap) of row group k3 (0 x0, 1 x1, 2 v) at tokens t, t + 1
+  // (t even): four consecutive values u[t-2 .. t+1] as two aligned 8-byte loads (reads start at multiples of 32
+  // tokens; slots between L and the end of the read's last 32-block are readable and masked here)
+  auto short2 = [&](int k3, const float* row, int t, float& o0, float& o1) {
+    const float w0 = a.sw[(k3 * D + c) * 3 + 0], w1 = a.sw[(k3 * D + c) * 3 + 1], w2 = a.sw[(k3 * D + c) * 3 + 2],
+                b = a.sb[k3 * D + c];
+    float um2 = 0.f, um1 = 0.f, u0, u1;
+    if (TAB) {
+      auto val = [&](int tt) -> float {
+        if (tt < 0 || tt >= L) return 0.f;
+        const unsigned id = tok[tt];
+        return s_tab[k3 * 17 + (id < 16u ? id : 16u)];
+      };
+      um2 = val(t - 2);
+      um1 = val(t - 1);
+      u0 = val(t);
+      u1 = val(t + 1);
+    } else {
+      if (t >= 2) {
+        const float2 lo = *reinterpret_cast<const float2*>(row + t - 2);
+        um2 = lo.x;
+        um1 = lo.y;
+      }
+      const float2 hi = *reinterpret_cast<const float2*>(row + t);
+      u0 = hi.x;
+      u1 = t + 1 < L ? hi.y : 0.f;
+    }
+    o0 = fmaf(w0, um2, fmaf(w1, um1, fmaf(w2, u0, b)));
+    o1 = fmaf(w0, um1, fmaf(w1, u0, fmaf(w2, u1, b)));
+  };
+
+  // ---- gated input, packed: c[m] = z[2m] + i z[2m+1] ----
+  for (int m = tid; m < M; m += T) {
+    const int t = 2 * m;
+    float2 z = make_float2(0.f, 0.f);
+    if (t < L) {
+      float a0, a1, b0, b1;
+      short2(1, ux1, t, a0, a1);
+      short2(2, uv, t, b0, b1);
+      z.x = a0 * b0;
+      z.y = t + 1 < L ? a1 * b1 : 0.f;
+    }
+    s[pad16(m)] = z;
+  }
+  __syncthreads();
+  fft_lds<LOGM>(s, tw, tid);
+
+  // ---- spectrum product and repacking for the inverse transform (stored conjugated: IFFT = conj . FFT . conj) ----
+  const float2* K = spec + (int64_t)c * (M + 1);
+  for (int kk = tid; kk <= M / 2; kk += T) {
+    const float2 ck = s[pad16(kk)], cmk = s[pad16((M - kk) & (M - 1))];
+    const float2 wk = tw[kk * (FFT_TW_N / (2 * M))];
+    float2 yk, ymk;
+    if (kk == 0) {
+      const float2 k0 = K[0], kn = K[M];
+      yk = make_float2((ck.x + ck.y) * k0.x, 0.f);   // Y[0]  (real)
+      ymk = make_float2((ck.x - ck.y) * kn.x, 0.f);  // Y[M]  (real)
+      // Ye[0] = (Y[0] + Y[M]) / 2, Yo[0] = (Y[0] - Y[M]) / 2; C'[0] = Ye + i Yo
+      s[pad16(0)] = make_float2(0.5f * (yk.x + ymk.x), -0.5f * (yk.x - ymk.x));  // conj(C'[0])
+    } else {
+      float2 zk, zmk;
+      unpack_pair<LOGM>(ck, cmk, wk, zk, zmk);
+      yk = cmul(zk, K[kk]);
+      ymk = cmul(zmk, K[M - kk]);
+      // Ye[k] = (Y[k] + conj(Y[M-k])) / 2,  Yo[k] = conj(W^k) (Y[k] - conj(Y[M-k])) / 2
+      const float2 b = cconj(ymk);
+      const float2 ye = make_float2(0.5f * (yk.x + b.x), 0.5f * (yk.y + b.y));
+      const float2 d = make_float2(0.5f * (yk.x - b.x), 0.5f * (yk.y - b.y));
+      const float2 yo = cmul(cconj(wk), d);
+      // C'[k] = Ye + i Yo ;  C'[M-k] = conj(Ye) + i conj(Yo)
+      const float2 cp = make_float2(ye.x - yo.y, ye.y + yo.x);
+      const float2 cq = make_float2(ye.x + yo.y, -ye.y + yo.x);
+      s[pad16(kk)] = cconj(cp);
+      if (kk != M / 2) s[pad16(M - kk)] = cconj(cq);
+    }
+  }
+  __syncthreads();
+  fft_lds<LOGM>(s, tw, tid);
+
+  // ---- y[t] = conv[t] * shortconv(x0)[t]: conv[2m] = Re r[m] / M, conv[2m+1] = -Im r[m] / M ----
+  const float inv_m = 1.0f / (float)M;
+  float* y = a.y + (int64_t)c * a.Tp + toff;
+  for (int m = tid; 2 * m < L; m += T) {
+    const int t = 2 * m;
+    const float2 rv = s[pad16(m)];
+    float g0, g1;
+    short2(0, ux0, t, g0, g1);
+    y[t] = rv.x * inv_m * g0;
+    if (t + 1 < L) y[t + 1] = -rv.y * inv_m * g1;
+  }
+}
+
+template <int LOGM>
+constexpr size_t fft_smem() {
+  return (size_t)((1 << LOGM) + (1 << LOGM) / 16) * sizeof(float2) + 64 * sizeof(float);
+}
+
+template <int LOGM>
+int launch_filter_t(hipStream_t st, const float* kf, int64_t kf_stride, int kf_taps, int D, const float2* tw, float2* spec) {
+  constexpr int T = (1 << LOGM) / 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hyena_fft_filter_kernel<LOGM>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_smem<LOGM>()));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(hyena_fft_filter_kernel<LOGM>, dim3(D), dim3(T), fft_smem<LOGM>(), st, kf, kf_stride, kf_taps, tw, spec);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+template <int LOGM, bool TAB>
+int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  constexpr int T = (1 << LOGM) / 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hyena_fft_kernel<LOGM, TAB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_smem<LOGM>()));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((hyena_fft_kernel<LOGM, TAB>), dim3(n_reads, a.D), dim3(T), fft_smem<LOGM>(), st, a, reads, tw, spec);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+}  // namespace
+
+int launch_fft_twiddles(hipStream_t st, float* tw) {
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_N / 256), dim3(256), 0, st, reinterpret_cast<float2*>(tw));
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+int fft_twiddle_count() { return FFT_TW_N; }
+
+int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t kf_stride, int kf_taps, int D,
+                            const float* tw, float* spec) {
+  const float2* t2 = reinterpret_cast<const float2*>(tw);
+  float2* s2 = reinterpret_cast<float2*>(spec);
+  switch (logm) {
+    case 11: return launch_filter_t<11>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 12: return launch_filter_t<12>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 13: return launch_filter_t<13>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 14: return launch_filter_t<14>(st, kf, kf_stride, kf_taps, D, t2, s2);
+  }
+  set_error("FFT long convolution: unsupported size 2^%d", logm);
+  return DC_ERR_UNSUPPORTED;
+}
+
+int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,
+                     const float* spec) {
+  if (n_reads <= 0) return DC_OK;
+  DC_REQUIRE(a.ntok && a.toff && a.u && a.y && a.sw && a.sb && reads && tw && spec, "FFT long convolution: null argument");
+  const float2* t2 = reinterpret_cast<const float2*>(tw);
+  const float2* s2 = reinterpret_cast<const float2*>(spec);
+  const bool tab = a.tok != nullptr;
+  switch (logm) {
+    case 11: return tab ? launch_fft_t<11, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<11, false>(st, a, reads, n_reads, t2, s2);
+    case 12: return tab ? launch_fft_t<12, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<12, false>(st, a, reads, n_reads, t2, s2);
+    case 13: return tab ? launch_fft_t<13, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<13, false>(st, a, reads, n_reads, t2, s2);
+    case 14: return tab ? launch_fft_t<14, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<14, false>(st, a, reads, n_reads, t2, s2);
+  }
+  set_error("FFT long convolution: unsupported size 2^%d", logm);
+  return DC_ERR_UNSUPPORTED;
+}
+
+}  // namespace dc

@@ -331,6 +331,10 @@ class HipModel:
         _lib.check(_lib.lib().dc_model_set_gemm_mode(self._h, {"f32": 0, "bf16x6": 1, "fp16x3": 2}[mode]))
         self.gemm_mode = mode
 
+    def set_fft_threshold(self, min_tokens: int):
+        """Reads with more than `min_tokens` tokens take the O(L log L) FFT long convolution (default 3072)."""
+        _lib.check(_lib.lib().dc_model_set_fft_threshold(self._h, int(min_tokens)))
+
     def set_mlp_fusion(self, level):
         """fp16x3.  0 / False: fc1 and fc2 as two GEMM launches; 1: fc1 -> GELU -> fc2 as one kernel;
         2 / True (default): that kernel also runs the GEMM that consumes LayerNorm(its output) -- the next

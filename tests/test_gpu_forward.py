@@ -410,3 +410,45 @@ def test_precision_robustness_vs_float64(hip_lib, case):
         assert errs["fp16x3_unchecked"] == errs["fp16x3"]
     assert errs["fp16x3"] <= 1e-3 * scale                      # north_star's tolerance, with margin to spare
     model.close()
+
+
+@pytest.mark.parametrize("L", [1500, 2048, 2049, 3000, 4097, 8192, 10001, 16384])
+def test_fft_long_convolution_matches_toeplitz_and_oracle(env, L):
+    """The O(L log L) FFT long convolution (reads above the length threshold, csrc/hyena_fft.hip) against the
+    block-Toeplitz MFMA kernel of the same build and against the oracle's `fftconv`: every transform size
+    (2^11 .. 2^14 complex points), lengths at and next to the size boundaries, and a ragged batch in which short
+    reads keep the MFMA kernel while long ones take the FFT."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(L)
+    ids, q = _inputs(rng, 1, L)
+    d_ids, d_q = ops.to_device(ids.astype(np.uint8)), ops.to_device(q)
+    try:
+        model.set_fft_threshold(1 << 20)
+        toep = model.forward(d_ids, d_q).cpu().numpy()
+        model.set_fft_threshold(1024)
+        model.set_profiling(True)
+        model.profile_reset()
+        fft = model.forward(d_ids, d_q).cpu().numpy()
+        stages = model.profile()
+        model.set_profiling(False)
+        assert stages.get("hyena_fft", (0, 0))[1] == 4, stages  # one launch per layer
+        ref = fr.forward(sd, ids, q).numpy()
+        _check(fft, ref)
+        _check(toep, ref)
+        assert np.abs(fft - toep).max() < 1e-4
+        # ragged: a short read (MFMA path) next to this one (FFT path), each equal to its own single-read result
+        Ls = 700
+        ids2 = np.full((2, L), 4, np.uint8)
+        q2 = np.zeros((2, L), np.float32)
+        i_s, q_s = _inputs(rng, 1, Ls)
+        ids2[0, L - Ls:], q2[0, L - Ls:] = i_s[0], q_s[0]
+        ids2[1], q2[1] = ids[0], q[0]
+        first, ntok = np.array([L - Ls, 0], np.int32), np.array([Ls, L], np.int32)
+        out = model.forward_ragged(ops.to_device(ids2), ops.to_device(q2), first, ntok).cpu().numpy()
+        assert np.abs(out[1] - fft[0]).max() < 2e-5
+        _check(out[0, L - Ls:], fr.forward(sd, i_s, q_s).numpy()[0])
+    finally:
+        model.set_fft_threshold(3072)
+        model.set_profiling(False)
