@@ -10,7 +10,13 @@
 //   bgzf::io::MultithreadedWriter usage       src/output/writefq.rs:252-276, src/bin/predict.rs:266-270
 #include "../../include/deepchopper_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+
+#include "fast_inflate.h"
 
 #include <atomic>
 #include <cerrno>
@@ -44,6 +50,17 @@ constexpr size_t kBlock = 4u << 20;  // decompressed / plain bytes handed from t
 // ------------------------------------------------------------------------------------------------
 // Source thread: file -> (inflate) -> bounded queue of byte blocks
 // ------------------------------------------------------------------------------------------------
+// A decompressed block on its way to the parser.  `marks`: gzip members that end inside the block, with the
+// CRC-32 / length their trailers promise -- the in-house inflater leaves the check to the consumer thread, so the
+// two threads share the per-byte work (zlib's own inflate checks internally and leaves `marks` empty).
+struct Mark {
+  uint32_t end, crc, isize;
+};
+struct Block {
+  std::vector<uint8_t> data;
+  std::vector<Mark> marks;
+};
+
 struct Source {
   FILE* fp = nullptr;
   bool compressed = false;
@@ -51,16 +68,22 @@ struct Source {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv_put, cv_get;
-  std::deque<std::vector<uint8_t>> q;
+  std::deque<Block> q;
   bool done = false, cancel = false;
   std::string err;
   std::atomic<int64_t> consumed{0};
+  std::atomic<bool> fast_crc{false};  // blocks come from the in-house inflater: the consumer keeps the running CRC-32
   // BGZF byte-range shards: compressed offset the stream starts at / the block boundary that ends the
   // range; range_end_u = (decompressed bytes emitted up to that boundary) + 1, published once reached
   int64_t start_off = 0, end_off = INT64_MAX;
   std::atomic<int64_t> range_end_u{INT64_MAX};
 
   void push(std::vector<uint8_t>&& b) {
+    Block blk;
+    blk.data = std::move(b);
+    push(std::move(blk));
+  }
+  void push(Block&& b) {
     std::unique_lock<std::mutex> lk(mu);
     cv_put.wait(lk, [&] { return (int)q.size() < depth || cancel; });
     if (cancel) return;
@@ -78,7 +101,7 @@ struct Source {
     return cancel;
   }
   // returns false at end of stream (err set on failure)
-  bool pop(std::vector<uint8_t>& out, std::string& e) {
+  bool pop(Block& out, std::string& e) {
     std::unique_lock<std::mutex> lk(mu);
     cv_get.wait(lk, [&] { return !q.empty() || done; });
     if (!q.empty()) {
@@ -170,8 +193,124 @@ struct Source {
     finish(e);
   }
 
+  // gzip / BGZF through the in-house decoder (fast_inflate.h) on a memory-mapped file.  Same contract as run_gzip:
+  // multi-member streams, trailing zero padding, CRC-32 and length of every member checked, BGZF range ends.
+  bool run_fast() {
+    const int fd = fileno(fp);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size <= 0) return false;
+    const size_t fsize = (size_t)sb.st_size;
+    void* map = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) return false;
+    madvise(map, fsize, MADV_SEQUENTIAL);
+    fast_crc.store(true);
+    const uint8_t* const base = (const uint8_t*)map;
+    const uint8_t* p = base + (start_off > 0 && (size_t)start_off < fsize ? (size_t)start_off : 0);
+    if (start_off >= (int64_t)fsize) p = base + fsize;
+    const uint8_t* const fend = base + fsize;
+    constexpr size_t WIN = 32768;
+    std::vector<uint8_t> buf(WIN + kBlock + dcio::FastInflate::SLACK + 64);
+    uint8_t* const out0 = buf.data() + WIN;
+    uint8_t* out = out0;
+    uint8_t* const out_limit = out0 + kBlock;
+    std::unique_ptr<dcio::FastInflate> inf(new dcio::FastInflate);
+    int64_t pushed = 0;
+    std::string e;
+    std::vector<Mark> marks;
+    auto flush = [&](bool all) {  // hand over [out0, out); keep the last 32 KiB as history
+      const size_t have = (size_t)(out - out0);
+      if (have == 0 && marks.empty()) return;
+      if (!all && have < kBlock) return;
+      Block blk;
+      blk.data.assign(out0, out);
+      blk.marks.swap(marks);
+      pushed += (int64_t)have;
+      push(std::move(blk));
+      const size_t keep = have < WIN ? have : WIN;
+      memmove(out0 - keep, out - keep, keep);
+      out = out0;
+    };
+    while (p < fend && !cancelled()) {
+      // between members: zero padding after the last one is tolerated (as gzip(1) does)
+      if (*p == 0) {
+        const uint8_t* q = p;
+        while (q < fend && *q == 0) ++q;
+        if (q == fend) {
+          consumed.store((int64_t)(fend - base) - (start_off > 0 ? start_off : 0));
+          break;
+        }
+        e = "inflate failed: invalid data after the gzip member";
+        break;
+      }
+      // ---- gzip member header (RFC 1952) ----
+      if (fend - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) { e = "inflate failed: incorrect header check"; break; }
+      const unsigned flg = p[3];
+      const uint8_t* q = p + 10;
+      bool ok = true;
+      if (flg & 4) {  // FEXTRA
+        if (fend - q < 2) ok = false;
+        else {
+          const size_t xlen = q[0] | (q[1] << 8);
+          q += 2;
+          if ((size_t)(fend - q) < xlen) ok = false;
+          else q += xlen;
+        }
+      }
+      for (int f = 8; ok && f <= 16; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
+        if (flg & f) {
+          while (q < fend && *q) ++q;
+          if (q >= fend) ok = false;
+          else ++q;
+        }
+      }
+      if (ok && (flg & 2)) {  // FHCRC
+        if (fend - q < 2) ok = false;
+        else q += 2;
+      }
+      if (!ok) { e = "unexpected end of gzip stream"; break; }
+      inf->set_input(q, fend);
+      inf->begin_member();
+      uint64_t member_out = 0;
+      uint8_t* seg = out;  // start of the not yet check-summed output of this member
+      bool member_done = false;
+      while (!cancelled()) {
+        const dcio::FastInflate::Status st = inf->run(out, out_limit, member_out + (uint64_t)(out - seg));
+        if (st == dcio::FastInflate::NEED_OUTPUT || st == dcio::FastInflate::MEMBER_END) {
+          member_out += (uint64_t)(out - seg);
+          if (st == dcio::FastInflate::MEMBER_END) { member_done = true; break; }
+          flush(false);
+          seg = out;
+          continue;
+        }
+        e = st == dcio::FastInflate::ERR_TRUNCATED ? "unexpected end of gzip stream" : std::string("inflate failed: ") + inf->error();
+        break;
+      }
+      if (!member_done) break;
+      const uint8_t* t = inf->input_pos();
+      if (fend - t < 8) { e = "unexpected end of gzip stream"; break; }
+      const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+      const uint32_t want_len = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (want_len != (uint32_t)member_out) { e = "inflate failed: incorrect length check"; break; }
+      marks.push_back(Mark{(uint32_t)(out - out0), want_crc, want_len});  // CRC-32: checked by the consumer
+      p = t + 8;
+      consumed.store((int64_t)(p - base) - (start_off > 0 ? start_off : 0));
+      if (range_end_u.load() == INT64_MAX && (int64_t)(p - base) >= end_off)
+        range_end_u.store(pushed + (int64_t)(out - out0) + 1);
+      if (out - out0 >= (ptrdiff_t)kBlock) flush(false);
+    }
+    if (e.empty()) flush(true);
+    munmap(map, fsize);
+    finish(e);
+    return true;
+  }
+
   void start() {
-    th = std::thread([this] { compressed ? run_gzip() : run_plain(); });
+    th = std::thread([this] {
+      if (!compressed) return run_plain();
+      const char* sel = getenv("DC_IO_INFLATE");
+      if (sel && strcmp(sel, "zlib") == 0) return run_gzip();
+      if (!run_fast()) run_gzip();  // not a regular file (pipe, ...): stream it through zlib
+    });
   }
   ~Source() {
     {
@@ -232,16 +371,33 @@ struct dc_fq_reader {
   }
 
   // appends the next block; false at end of stream (rc set on a source error)
+  uint32_t crc_run = 0;  // CRC-32 of the current gzip member so far (members checked on this thread)
   bool more(int& rc) {
     if (eof) return false;
-    std::vector<uint8_t> b;
+    Block b;
     std::string e;
     if (!src.pop(b, e)) {
       eof = true;
       if (!e.empty()) rc = fail(DC_FQ_ERR_IO, "%s: %s", path.c_str(), e.c_str());
       return false;
     }
-    buf.insert(buf.end(), b.begin(), b.end());
+    if (!b.marks.empty()) {
+      size_t pos = 0;
+      for (const Mark& m : b.marks) {
+        crc_run = (uint32_t)crc32(crc_run, b.data.data() + pos, (uInt)(m.end - pos));
+        pos = m.end;
+        if (crc_run != m.crc) {
+          eof = true;
+          rc = fail(DC_FQ_ERR_IO, "%s: inflate failed: incorrect data check", path.c_str());
+          return false;
+        }
+        crc_run = 0;
+      }
+      crc_run = (uint32_t)crc32(crc_run, b.data.data() + pos, (uInt)(b.data.size() - pos));
+    } else if (src.fast_crc) {
+      crc_run = (uint32_t)crc32(crc_run, b.data.data(), (uInt)b.data.size());
+    }
+    buf.insert(buf.end(), b.data.begin(), b.data.end());
     return true;
   }
 

@@ -122,6 +122,45 @@ def chop_bench(args):
     os.remove(path)
 
 
+def feeder_bench(args):
+    """How fast can ONE process parse (and inflate) a FASTQ and deal its chunks to N per-GPU workers?  The ceiling of
+    `deepchopper predict --gpus N` on plain gzip input (the parent is the node's single inflater)."""
+    import threading
+
+    from deepchopper_amd import launcher, synth
+
+    tmp = tempfile.mkdtemp(prefix="dc_feed_")
+    path = os.path.join(tmp, "reads.fq")
+    with _opener(args.container, path) as fh:
+        for b0 in range(0, args.reads, 10_000):
+            n = min(10_000, args.reads - b0)
+            seq, qual, ids = synth.synth_reads_fixed(n, args.bp, seed=42 + b0, start_index=b0)
+            fh.write(synth.to_fastq(seq, qual, ids))
+    feeder = launcher.ChunkFeeder(path, args.gpus, args.max_reads, args.max_reads * (args.bp + 1))
+    got = [0] * args.gpus
+
+    def consume(i, fd):
+        for c in launcher.PipeChunks(fd):
+            got[i] += c.n
+
+    fds = [os.dup(fd) for fd in feeder.read_fds]  # start() closes the parent's copies of the read ends
+    ths = [threading.Thread(target=consume, args=(i, fd)) for i, fd in enumerate(fds)]
+    t0 = time.time()
+    feeder.start()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    feeder.join()
+    dt = time.time() - t0
+    print(json.dumps({"what": "single reader/inflater feeding N consumers over pipes (no GPU)", "container": args.container,
+                      "consumers": args.gpus, "reads": sum(got), "bp": args.bp, "seconds": round(dt, 2),
+                      "aggregate_reads_per_s": round(sum(got) / dt), "MB_per_s_uncompressed": round(sum(got) * (2 * args.bp + 20) / 1e6 / dt),
+                      "host_cpus": os.cpu_count()}))
+    os.remove(path)
+    os.rmdir(tmp)
+
+
 def ref_batch_bench(args):
     """`deepchopper predict -b 12` shape: tiny left-padded batches, where per-batch host waits dominate.  Same
     stream twice: pipelined (non-blocking pinned copies, results on a copy stream) and serialised (every batch
@@ -173,11 +212,15 @@ def main():
     ap.add_argument("--cli", action="store_true", help="--chop through the command line even on one GPU")
     ap.add_argument("--threads", type=int, default=4, help="BGZF compression workers of the chop output")
     ap.add_argument("--no-count", action="store_true")
+    ap.add_argument("--feeder-only", action="store_true", help="host side of a multi-GPU plain-gzip run: the parent's single "
+                    "reader / inflater dealing chunks to --gpus consumers that discard them (no GPU work): aggregate reads/s")
     ap.add_argument("--ref-batch", type=int, default=0, help="reference-compatible mode: batches of this many reads "
                     "(the reference's -b 12), left-padded, int64 ids; reports reads/s pipelined and serialised")
     args = ap.parse_args()
     if args.ref_batch:
         return ref_batch_bench(args)
+    if args.feeder_only:
+        return feeder_bench(args)
     if args.chop:
         if args.max_reads == 2048:
             args.max_reads = 8192
