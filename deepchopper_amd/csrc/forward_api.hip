@@ -36,7 +36,7 @@ struct LayerDev {
   unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
   unsigned short* kfq = nullptr;  // fp16 planes (2) of the per-channel scaled filter
   float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
-  float* kspec[4] = {nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 11..14
+  float* kspec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 10..14
 };
 
 struct ProfEvent {
@@ -64,11 +64,11 @@ struct dc_model {
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
-  bool kspec_valid[4] = {false, false, false, false};  // spectra match the materialised filters
+  bool kspec_valid[5] = {false, false, false, false, false};  // spectra match the materialised filters
   int fft_min_tokens = 3072;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
   // FFT buckets of the cached geometry: read lists by transform size
   int32_t* d_fft_reads = nullptr;
-  int fft_count[4] = {0, 0, 0, 0}, fft_offset[4] = {0, 0, 0, 0};
+  int fft_count[5] = {0, 0, 0, 0, 0}, fft_offset[5] = {0, 0, 0, 0, 0};
   int max_P_mfma = 0;
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
@@ -317,8 +317,8 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
 
 // Filter spectra of every layer for transforms of 2^logm complex points (built once per materialised filter).
 int ensure_fft_spectra(dc_model* m, hipStream_t st, int logm) {
-  const int b = logm - 11;
-  DC_REQUIRE(b >= 0 && b < 4, "FFT size out of range");
+  const int b = logm - 10;
+  DC_REQUIRE(b >= 0 && b < 5, "FFT size out of range");
   if (!m->fft_tw) {
     DC_HIP_CHECK(hipMalloc((void**)&m->fft_tw, (size_t)fft_twiddle_count() * 2 * sizeof(float)));
     int rc = launch_fft_twiddles(st, m->fft_tw);
@@ -451,13 +451,13 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   std::vector<int32_t> order(n_reads);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
-  std::vector<int32_t> fft_lists[4], mfma_order;
+  std::vector<int32_t> fft_lists[5], mfma_order;
   for (int j = 0; j < n_reads; ++j) {
     const int r = order[j], nt = h_ntok[r];
     if (nt > m->fft_min_tokens && nt <= (1 << 14)) {
-      int logm = 11;
+      int logm = 10;
       while ((1 << logm) < nt) ++logm;
-      fft_lists[logm - 11].push_back(r);
+      fft_lists[logm - 10].push_back(r);
     } else {
       mfma_order.push_back(r);
     }
@@ -472,7 +472,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     maxP_mfma = std::max(maxP_mfma, nblk[mfma_order[j]]);
   }
   std::vector<int32_t> fft_reads;
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < 5; ++b) {
     m->fft_offset[b] = (int)fft_reads.size();
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
@@ -593,8 +593,8 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
   if ((rc = ensure_workspace(m, m->Tp))) return rc;
   if ((rc = ensure_filters(m, st, (int64_t)m->max_P * 32))) return rc;
-  for (int b = 0; b < 4; ++b)
-    if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 11 + b))) return rc;
+  for (int b = 0; b < 5; ++b)
+    if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
 
   const int D = c.d_model, DI = c.d_inner, H = c.head_hidden;
   float* x = (float*)m->x.p;
@@ -690,10 +690,10 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         if (rc) return rc;
       }
       // long reads: O(L log L) FFT convolution, one launch per transform size present in the batch
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < 5; ++b) {
         if (m->fft_count[b] == 0) continue;
         ProfScope pf(m, st, "hyena_fft");
-        if ((rc = launch_hyena_fft(st, a, 11 + b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
+        if ((rc = launch_hyena_fft(st, a, 10 + b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
           return rc;
       }
     }
@@ -792,7 +792,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   m->cfg = *cfg;
   if (const char* e = getenv("DC_GEMM_MODE"))
     m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : ((strcmp(e, "fp16x3") == 0 || strcmp(e, "2") == 0) ? 2 : 1);
-  if (const char* e = getenv("DC_FFT_MIN")) m->fft_min_tokens = std::max(1024, atoi(e));
+  if (const char* e = getenv("DC_FFT_MIN")) m->fft_min_tokens = std::max(256, atoi(e));
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
   {
@@ -1018,7 +1018,7 @@ extern "C" int dc_model_overflow(dc_model* m, void* stream, int32_t* count) {
 
 extern "C" int dc_model_set_fft_threshold(dc_model* m, int32_t min_tokens) {
   DC_REQUIRE(m, "null pointer");
-  DC_REQUIRE(min_tokens >= 1024, "the FFT long convolution takes reads of more than 1024 tokens (min_tokens >= 1024; a value above the model's context disables it)");
+  DC_REQUIRE(min_tokens >= 256, "the FFT long convolution takes reads of more than min_tokens >= 256 tokens (a value above the model's context disables it)");
   m->fft_min_tokens = min_tokens;
   return DC_OK;
 }

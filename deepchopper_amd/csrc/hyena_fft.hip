@@ -158,7 +158,9 @@ __device__ __forceinline__ void fft_lds(float2* __restrict__ s, const float2* __
   // radices: 16 while they fit, then the rest (2, 4 or 8)
   fft_pass<LOGM, 16>(s, tw, 1, tid);
   fft_pass<LOGM, 16>(s, tw, 16, tid);
-  if constexpr (LOGM == 11) {
+  if constexpr (LOGM == 10) {
+    fft_pass<LOGM, 4>(s, tw, 256, tid);
+  } else if constexpr (LOGM == 11) {
     fft_pass<LOGM, 8>(s, tw, 256, tid);
   } else {
     fft_pass<LOGM, 16>(s, tw, 256, tid);
@@ -378,6 +380,7 @@ int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t k
   const float2* t2 = reinterpret_cast<const float2*>(tw);
   float2* s2 = reinterpret_cast<float2*>(spec);
   switch (logm) {
+    case 10: return launch_filter_t<10>(st, kf, kf_stride, kf_taps, D, t2, s2);
     case 11: return launch_filter_t<11>(st, kf, kf_stride, kf_taps, D, t2, s2);
     case 12: return launch_filter_t<12>(st, kf, kf_stride, kf_taps, D, t2, s2);
     case 13: return launch_filter_t<13>(st, kf, kf_stride, kf_taps, D, t2, s2);
@@ -395,6 +398,7 @@ int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t
   const float2* s2 = reinterpret_cast<const float2*>(spec);
   const bool tab = a.tok != nullptr;
   switch (logm) {
+    case 10: return tab ? launch_fft_t<10, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<10, false>(st, a, reads, n_reads, t2, s2);
     case 11: return tab ? launch_fft_t<11, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<11, false>(st, a, reads, n_reads, t2, s2);
     case 12: return tab ? launch_fft_t<12, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<12, false>(st, a, reads, n_reads, t2, s2);
     case 13: return tab ? launch_fft_t<13, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<13, false>(st, a, reads, n_reads, t2, s2);
