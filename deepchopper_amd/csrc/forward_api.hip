@@ -822,7 +822,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     if (D % 16 == 0) {  // k order of the fused MLP kernel's third GEMM
       std::vector<float> Wtp((size_t)D * 3 * D);
       for (int k = 0; k < D; ++k)
-        memcpy(&Wtp[(size_t)k * 3 * D], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * 3 * D], (size_t)3 * D * sizeof(float));
+        memcpy(&Wtp[(size_t)k * 3 * D], &Wt[(size_t)(mlp_fused_perm(k)) * 3 * D], (size_t)3 * D * sizeof(float));
       float is_p = 0.f;
       UP(upload_planes_f16(m, Wtp, D, 3 * D, &L.Wq_inp, &is_p));
     }
@@ -865,7 +865,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     if (DI % 16 == 0) {  // fused MLP: logical k index 16 b + kappa stands for hidden unit 16 b + perm16(kappa)
       std::vector<float> Wtp((size_t)DI * D);
       for (int k = 0; k < DI; ++k)
-        memcpy(&Wtp[(size_t)k * D], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * D], (size_t)D * sizeof(float));
+        memcpy(&Wtp[(size_t)k * D], &Wt[(size_t)(mlp_fused_perm(k)) * D], (size_t)D * sizeof(float));
       float is_p = 0.f;
       UP(upload_planes_f16(m, Wtp, DI, D, &L.Wq_fc2p, &is_p));  // same values, same power-of-two scale as Wq_fc2
     }
@@ -892,7 +892,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   if (D % 16 == 0) {
     std::vector<float> Wtp((size_t)D * H);
     for (int k = 0; k < D; ++k)
-      memcpy(&Wtp[(size_t)k * H], &Wt[(size_t)((k & ~15) + mlp_fused_perm16(k & 15)) * H], (size_t)H * sizeof(float));
+      memcpy(&Wtp[(size_t)k * H], &Wt[(size_t)(mlp_fused_perm(k)) * H], (size_t)H * sizeof(float));
     float is_p = 0.f;
     UP(upload_planes_f16(m, Wtp, D, H, &m->Wq_l1p, &is_p));
   }

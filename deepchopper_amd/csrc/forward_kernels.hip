@@ -1046,13 +1046,24 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
         afr[1][1] = lds_read_b128<(4 * M_HC + 1 * 32) * 16>(aA);
         lds_wait<4>(xb[0], xb[1], xb[2], xb[3]);
         float x[8];
+        svec bs[2];
+#ifdef DC_ABL_M_NOSPLIT1  // ablation: what the type-1 steps would cost with LN(x) pre-split (cvt only, wrong results)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[2 * j] = xb[j][0];
+          x[2 * j + 1] = xb[j][1];
+          const f16x2 hp = __builtin_convertvector(xb[j], f16x2);
+          bs[0][2 * j] = hp[0]; bs[0][2 * j + 1] = hp[1];
+        }
+        bs[1] = bs[0];
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           x[2 * j] = fmaf(xb[j][0], rs, nm);
           x[2 * j + 1] = fmaf(xb[j][1], rs, nm);
         }
-        svec bs[2];
         SM::split_mx(x, bs, mx);
+#endif
         auto group = [&](auto mc, u32x4 (&f)[2]) {
           constexpr int mi = decltype(mc)::value;
           const svec af[2] = {__builtin_bit_cast(svec, f[0]), __builtin_bit_cast(svec, f[1])};
@@ -1106,7 +1117,17 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
           hv[j] = TANH ? gelu_tanh(v) : gelu_erf(v);
         }
         svec hf[2];
+#ifdef DC_ABL_M_NOGELU2  // ablation: the type-2 steps without GELU and split (cvt only, wrong results)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const f32x2 v2 = {acc1[mi][8 * q + j], acc1[mi][8 * q + j + 1]};
+          const f16x2 hp = __builtin_convertvector(v2, f16x2);
+          hf[0][j] = hp[0]; hf[0][j + 1] = hp[1];
+        }
+        hf[1] = hf[0];
+#else
         SM::split_mx(hv, hf, mx);
+#endif
         // A fragments of the 8 output tiles: one tile (2 reads) per batch, one batch ahead of its MFMAs
         const uint32_t aW = lds0 + cur * M_SLOT + ((2 * q + h) * M_D + i) * 16;
         u32x4 wf[2][2];  // [batch parity][plane]
@@ -1305,6 +1326,13 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
 }
 
 #include "mlp4_kernel.inc"
+#include "mlp16_kernel.inc"
+
+bool mlp_shape16() {
+  static const bool on = getenv("DC_MLP_SHAPE") && atoi(getenv("DC_MLP_SHAPE")) == 16;
+  return on;
+}
+int mlp_fused_perm(int k) { return mlp_shape16() ? (k & ~31) + mlp16_perm32(k & 31) : (k & ~15) + mlp_perm16(k & 15); }
 
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
@@ -1336,6 +1364,21 @@ int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
     return DC_OK;
   }
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
+  if (mlp_shape16()) {
+    if (g.Wp3 && g.epi3 == EPI_BIAS) {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp16_kernel<true, EPI_BIAS>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((mlp16_kernel<false, EPI_BIAS>), grid, block, 0, st, g);
+    } else if (g.Wp3) {
+      if (g.gelu_tanh) hipLaunchKernelGGL((mlp16_kernel<true, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((mlp16_kernel<false, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
+    } else if (g.gelu_tanh) {
+      hipLaunchKernelGGL((mlp16_kernel<true, -1>), grid, block, 0, st, g);
+    } else {
+      hipLaunchKernelGGL((mlp16_kernel<false, -1>), grid, block, 0, st, g);
+    }
+    DC_LAUNCH_CHECK();
+    return DC_OK;
+  }
   if (g.Wp3) {
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
                "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
