@@ -102,8 +102,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
 // squares in, st_sum / st_sq = the new statistics out (same buffers, overwritten)
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g);
 int mlp_fused_perm16(int kappa);
-int mlp_fused_perm(int k);       // k order of the fused MLP kernel's register-fed GEMMs (depends on its MFMA shape, $DC_MLP_SHAPE)
-bool mlp_shape16();              // $DC_MLP_SHAPE=16: the v_mfma_f32_16x16x32_f16 form of the fused MLP kernel  // hidden unit (within an aligned 16-group) that logical k index kappa stands for
+int mlp_fused_perm(int k);       // k order of the fused MLP kernel's register-fed GEMMs: real row that logical k stands for
 int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (partials of EPI_HEAD2_FUSED)
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);

@@ -1326,13 +1326,9 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
 }
 
 #include "mlp4_kernel.inc"
-#include "mlp16_kernel.inc"
-
-bool mlp_shape16() {
-  static const bool on = getenv("DC_MLP_SHAPE") && atoi(getenv("DC_MLP_SHAPE")) == 16;
-  return on;
-}
-int mlp_fused_perm(int k) { return mlp_shape16() ? (k & ~31) + mlp16_perm32(k & 31) : (k & ~15) + mlp_perm16(k & 15); }
+// k order of the fused MLP kernel's register-fed GEMMs.  (A v_mfma_f32_16x16x32_f16 form of the kernel with a
+// 32-group permutation was measured 15 % slower -- commit 8d24a79, profiles/r02_mlp_shape16_and_valu_ablations.json.)
+int mlp_fused_perm(int k) { return (k & ~15) + mlp_perm16(k & 15); }
 
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
@@ -1364,21 +1360,6 @@ int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
     return DC_OK;
   }
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
-  if (mlp_shape16()) {
-    if (g.Wp3 && g.epi3 == EPI_BIAS) {
-      if (g.gelu_tanh) hipLaunchKernelGGL((mlp16_kernel<true, EPI_BIAS>), grid, block, 0, st, g);
-      else hipLaunchKernelGGL((mlp16_kernel<false, EPI_BIAS>), grid, block, 0, st, g);
-    } else if (g.Wp3) {
-      if (g.gelu_tanh) hipLaunchKernelGGL((mlp16_kernel<true, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
-      else hipLaunchKernelGGL((mlp16_kernel<false, EPI_BIAS_RELU_Q>), grid, block, 0, st, g);
-    } else if (g.gelu_tanh) {
-      hipLaunchKernelGGL((mlp16_kernel<true, -1>), grid, block, 0, st, g);
-    } else {
-      hipLaunchKernelGGL((mlp16_kernel<false, -1>), grid, block, 0, st, g);
-    }
-    DC_LAUNCH_CHECK();
-    return DC_OK;
-  }
   if (g.Wp3) {
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
                "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
