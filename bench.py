@@ -196,7 +196,14 @@ def main():
         import torch.distributed as dist
 
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            except Exception as e:  # the group only carries the barrier and one scalar max: gloo does that as well
+                print(f"[bench] rank {rank}: RCCL process group failed ({type(e).__name__}: {e}); control plane on gloo",
+                      file=sys.stderr)
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
 
@@ -366,7 +373,8 @@ def main():
             "config": {"workload": f"configs[1]: synthetic {L}-bp reads, {world}xMI355X, batches of {B} reads per GPU "
                                    f"(tokenise -> HyenaDNA forward -> argmax/smooth/intervals), synthetic weights",
                        "reads_per_step_per_gpu": B, "read_len": L, "tokens_per_read": L + 1,
-                       "parallelism": f"read-sharded x{world}, no collectives"},
+                       "parallelism": f"read-sharded x{world}, no collectives",
+                       "control_plane": (backend if world > 1 else "none") + " (barrier + max of one host scalar)"},
             "roofline": roof,
             "value_bf16x6": strict["value"] if strict else None,
             "bf16x6_leg": strict,
