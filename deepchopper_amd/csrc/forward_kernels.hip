@@ -817,7 +817,17 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
           x[2 * j + 1] = LN ? fmaf(xb[j][1], rs[0], nm[0]) : xb[j][1];
         }
         svec bs[2];
+#ifdef DC_ABL_H_NOSPLIT  // ablation: B operand as if it arrived pre-split (cvt only, wrong results)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 v2 = {x[2 * j], x[2 * j + 1]};
+          const f16x2 hp = __builtin_convertvector(v2, f16x2);
+          bs[0][2 * j] = hp[0]; bs[0][2 * j + 1] = hp[1];
+        }
+        bs[1] = bs[0];
+#else
         SM::split_mx(x, bs, mx);
+#endif
         static_for<H_MI>([&](auto mc) {
           constexpr int mi = decltype(mc)::value;
           lds_wait<2 * (H_MI - 1 - mi)>(afr[mi][0], afr[mi][1]);
