@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -59,6 +60,197 @@ struct Mark {
 struct Block {
   std::vector<uint8_t> data;
   std::vector<Mark> marks;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Parallel inflate of ONE large gzip member (a plain `.fastq.gz` has a single DEFLATE stream, which cannot be
+// split without decoding it).  The compressed range is cut into chunks; a worker thread
+//   1. finds the first dynamic-Huffman block header at or after its chunk's byte offset by scanning bit positions
+//      (FastInflate::probe_text_block: strict header check + a trial decode that must yield text),
+//   2. decodes from there up to the start the next chunk found, as 16-bit symbols behind a 32 768-entry prefix of
+//      placeholders (256 + j = "byte j of the 32 KiB before this chunk"): back-references into the unseen window
+//      simply copy placeholders.
+// The coordinator takes chunks in stream order.  A chunk counts only if it starts exactly where its predecessor
+// ended (the predecessor was decoded from a confirmed position, so its block boundaries are the true ones -- by
+// induction from chunk 0 the result is the sequential decode, bit for bit; a start that is not confirmed is
+// discarded and that stretch is decoded again sequentially).  Placeholders are resolved through a 33 024-entry
+// byte table (identity + the previous chunk's last 32 KiB).  CRC-32 / ISIZE are checked as in the serial path.
+// ------------------------------------------------------------------------------------------------
+class ParInflate {
+ public:
+  struct Chunk {
+    uint64_t start_bit = 0, end_bit = 0;
+    bool ended = false;   // the member's final block was decoded: end_bit is the (byte aligned) position of the trailer
+    bool failed = false;  // decode error (a false start, or corrupt data: the sequential re-decode decides which)
+    std::unique_ptr<uint16_t[]> sym;  // 32 768 placeholders + symbols (not value-initialised: tens of MB per chunk)
+    size_t n_out = 0;
+  };
+  static constexpr size_t SOFT_MAX = 48u << 20;  // symbols per chunk before a worker stops at the next block boundary
+  static constexpr uint64_t NONE = ~0ull;
+  static constexpr int TRIAL = 2048;
+
+  ParInflate(const uint8_t* origin, const uint8_t* end, int threads, size_t chunk_bytes, std::function<bool()> cancelled)
+      : origin_(origin), end_(end), chunk_bytes_(chunk_bytes), cancelled_(std::move(cancelled)) {
+    total_bits_ = (uint64_t)(end - origin) * 8;
+    n_ = (int)(((size_t)(end - origin) + chunk_bytes - 1) / chunk_bytes);
+    starts_.assign((size_t)n_ + 1, NONE);
+    start_state_.assign((size_t)n_ + 1, 0);
+    chunks_.resize((size_t)n_);
+    ready_.assign((size_t)n_, 0);
+    window_ = 2 * threads + 1;
+    for (int t = 0; t < threads; ++t) workers_.emplace_back([this] { work(); });
+  }
+  ~ParInflate() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    for (auto& w : workers_) w.join();
+  }
+  int n_chunks() const { return n_; }
+  // chunk i, decoded (blocks); nullptr when cancelled
+  Chunk* wait(int i) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return ready_[(size_t)i] || stop_; });
+    return ready_[(size_t)i] ? &chunks_[(size_t)i] : nullptr;
+  }
+  // the coordinator is done with chunks < i: free them, let the workers run further ahead
+  void release_upto(int i) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (int k = released_; k < i && k < n_; ++k) chunks_[(size_t)k].sym.reset();
+    if (i > released_) released_ = i;
+    cv_.notify_all();
+  }
+  // first detected block start at or after chunk j's byte offset (memoised; total_bits = none before the end)
+  uint64_t start_of(int j) {
+    if (j <= 0) return 0;
+    if (j >= n_) return total_bits_;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return start_state_[(size_t)j] != 1 || stop_; });
+      if (start_state_[(size_t)j] == 2 || stop_) return starts_[(size_t)j];
+      start_state_[(size_t)j] = 1;
+    }
+    const uint64_t s = scan((uint64_t)j * chunk_bytes_ * 8);
+    std::lock_guard<std::mutex> lk(mu_);
+    starts_[(size_t)j] = s;
+    start_state_[(size_t)j] = 2;
+    cv_.notify_all();
+    return s;
+  }
+
+ private:
+  const uint8_t* origin_;
+  const uint8_t* end_;
+  size_t chunk_bytes_;
+  std::function<bool()> cancelled_;
+  uint64_t total_bits_ = 0;
+  int n_ = 0, next_ = 0, released_ = 0, window_ = 0;
+  bool stop_ = false;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<uint64_t> starts_;
+  std::vector<char> start_state_;  // 0 unknown, 1 being computed, 2 known
+  std::vector<Chunk> chunks_;
+  std::vector<char> ready_;
+  std::vector<std::thread> workers_;
+
+  static uint64_t load64(const uint8_t* p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+  }
+  uint64_t scan(uint64_t from_bit) {
+    std::unique_ptr<dcio::FastInflate> probe(new dcio::FastInflate);
+    std::vector<uint16_t> scratch(32768 + TRIAL + dcio::FastInflate::SLACK + 16);
+    // a header needs 17 bits + up to 19 x 3: stop while 16 readable bytes remain (the tail belongs to the previous chunk)
+    const uint64_t last = total_bits_ > 160 ? total_bits_ - 160 : 0;
+    unsigned tick = 0;
+    for (uint64_t p = from_bit; p < last; ++p) {
+      const uint8_t* b8 = origin_ + (p >> 3);
+      const uint64_t b = load64(b8) >> (p & 7);  // >= 57 valid bits
+      if ((b & 7) != 4) continue;                // BFINAL = 0, BTYPE = 2
+      if (((b >> 3) & 31) > 29 || ((b >> 8) & 31) > 29) continue;
+      const int hclen = (int)((b >> 13) & 15) + 4;
+      // code-length code: complete prefix code over lengths 1..7 <=> sum 2^(7 - len) == 128
+      int kraft = 0;
+      const int n1 = hclen < 13 ? hclen : 13;  // 17 + 13 * 3 = 56 bits from the first word
+      uint64_t w = b >> 17;
+      for (int k = 0; k < n1; ++k, w >>= 3)
+        if (w & 7) kraft += 128 >> (w & 7);
+      if (hclen > 13) {
+        const uint64_t p2 = p + 56;
+        uint64_t w2 = load64(origin_ + (p2 >> 3)) >> (p2 & 7);
+        for (int k = 13; k < hclen; ++k, w2 >>= 3)
+          if (w2 & 7) kraft += 128 >> (w2 & 7);
+      }
+      if (kraft != 128) continue;
+      if (probe->probe_text_block(origin_, p, end_, scratch.data(), TRIAL)) return p;
+      if ((++tick & 63) == 0 && cancelled_()) break;
+    }
+    return total_bits_;
+  }
+
+  void work() {
+    std::unique_ptr<dcio::FastInflate> inf(new dcio::FastInflate);
+    for (;;) {
+      int i;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || next_ >= n_ || next_ < released_ + window_; });
+        if (stop_ || next_ >= n_) return;
+        i = next_++;
+      }
+      Chunk c;
+      c.start_bit = start_of(i);
+      const uint64_t stop_bit = start_of(i + 1);
+      if (c.start_bit >= stop_bit && i > 0) {
+        c.end_bit = c.start_bit;  // no block starts inside this chunk: the previous chunk runs through it
+      } else {
+        decode(*inf, c, i + 1 < n_ ? stop_bit : dcio::FastInflate::NO_STOP);
+      }
+      std::lock_guard<std::mutex> lk(mu_);
+      chunks_[(size_t)i] = std::move(c);
+      ready_[(size_t)i] = 1;
+      cv_.notify_all();
+    }
+  }
+
+  void decode(dcio::FastInflate& inf, Chunk& c, uint64_t stop_bit) {
+    if (!inf.seek_bit(origin_, c.start_bit, end_)) { c.failed = true; return; }
+    constexpr size_t PAD = dcio::FastInflate::SLACK + 16;
+    size_t cap = 32768 + chunk_bytes_ * 3;
+    c.sym.reset(new uint16_t[cap + PAD]);
+    for (int j = 0; j < 32768; ++j) c.sym[(size_t)j] = (uint16_t)(256 + j);
+    size_t n = 32768;
+    unsigned tick = 0;
+    for (;;) {
+      uint16_t* out = c.sym.get() + n;
+      const dcio::FastInflate::Status st = inf.run_t<uint16_t>(out, c.sym.get() + cap, (uint64_t)n, stop_bit);
+      n = (size_t)(out - c.sym.get());
+      if (st == dcio::FastInflate::NEED_OUTPUT) {
+        if ((++tick & 3) == 0 && cancelled_()) { c.failed = true; return; }
+        // far more output than expected (or no later start was found): end the chunk at the next block boundary,
+        // the coordinator carries on from there
+        if (n - 32768 > SOFT_MAX && stop_bit > inf.bit_pos()) stop_bit = inf.bit_pos();
+        const size_t ncap = cap + cap / 2;
+        std::unique_ptr<uint16_t[]> bigger(new uint16_t[ncap + PAD]);
+        memcpy(bigger.get(), c.sym.get(), n * sizeof(uint16_t));
+        c.sym = std::move(bigger);
+        cap = ncap;
+        continue;
+      }
+      if (st == dcio::FastInflate::BLOCK_STOP || st == dcio::FastInflate::MEMBER_END) {
+        c.ended = st == dcio::FastInflate::MEMBER_END;
+        c.end_bit = c.ended ? (uint64_t)(inf.input_pos() - origin_) * 8 : inf.bit_pos();
+        c.n_out = n - 32768;
+        return;
+      }
+      c.failed = true;
+      return;
+    }
+  }
 };
 
 struct Source {
@@ -193,6 +385,132 @@ struct Source {
     finish(e);
   }
 
+  static void append_window(std::vector<uint8_t>& win, const uint8_t* d, size_t n) {
+    constexpr size_t W = 32768;
+    if (n >= W) {
+      win.assign(d + n - W, d + n);
+    } else {
+      if (win.size() + n > W) win.erase(win.begin(), win.begin() + (ptrdiff_t)(win.size() + n - W));
+      win.insert(win.end(), d, d + n);
+    }
+  }
+
+  // Coordinator of ParInflate for the member whose DEFLATE stream starts at q.  Pushes the member's bytes in order
+  // (the last block carries the CRC mark).  Returns false with `e` set on a data error; trailer = nullptr when
+  // cancelled; otherwise trailer points at the member's CRC-32 / ISIZE.
+  bool inflate_member_parallel(const uint8_t* q, const uint8_t* fend, int threads, size_t chunk_bytes, uint64_t& member_out,
+                               const uint8_t*& trailer, int64_t& pushed, std::string& e) {
+    ParInflate par(q, fend, threads, chunk_bytes, [this] { return cancelled(); });
+    std::vector<uint8_t> win;  // last <= 32 KiB of this member's output
+    std::vector<uint8_t> tab(256 + 32768);
+    for (int k = 0; k < 256; ++k) tab[(size_t)k] = (uint8_t)k;
+    uint64_t expected = 0;  // bit position (from q) where the next confirmed block starts
+    bool ended = false;
+    std::unique_ptr<dcio::FastInflate> seq;
+    auto finish_member = [&](Block& blk) -> bool {  // trailer check + CRC mark on the member's last block
+      const uint8_t* t = q + (expected >> 3);
+      if (fend - t < 8) { e = "unexpected end of gzip stream"; return false; }
+      const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+      const uint32_t want_len = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+      if (want_len != (uint32_t)member_out) { e = "inflate failed: incorrect length check"; return false; }
+      blk.marks.push_back(Mark{(uint32_t)blk.data.size(), want_crc, want_len});
+      trailer = t;
+      return true;
+    };
+    auto deliver = [&](Block& blk) -> bool {  // bookkeeping + trailer check on the member's last block, then queue it
+      append_window(win, blk.data.data(), blk.data.size());
+      member_out += blk.data.size();
+      pushed += (int64_t)blk.data.size();
+      if (ended && !finish_member(blk)) return false;
+      push(std::move(blk));
+      return true;
+    };
+    const int n = par.n_chunks();
+    int i = 0;
+    uint64_t n_par = 0, n_ser = 0, b_par = 0, b_ser = 0;  // $DC_IO_DEBUG: how the member was decoded
+    while (!ended) {
+      if (cancelled()) return true;  // trailer stays null
+      // chunks whose detected start lies behind the confirmed position, or that contain no block start, are skipped
+      while (i < n && (par.start_of(i) < expected || par.start_of(i) >= par.start_of(i + 1))) ++i;
+      par.release_upto(i);
+      if (i < n && par.start_of(i) == expected) {
+        ParInflate::Chunk* c = par.wait(i);
+        if (!c) return true;
+        if (!c->failed) {
+          // confirmed start: resolve the placeholders through (identity | previous 32 KiB)
+          const size_t w = win.size();
+          memset(tab.data() + 256, 0, 32768);
+          if (w) memcpy(tab.data() + 256 + (32768 - w), win.data(), w);
+          const unsigned min_ok = 256 + (unsigned)(32768 - w);
+          Block blk;
+          blk.data.resize(c->n_out);
+          const uint16_t* sy = c->sym.get() + 32768;
+          uint8_t* o = blk.data.data();
+          unsigned bad = 0;
+          for (size_t k = 0; k < c->n_out; ++k) {
+            const unsigned v = sy[k];
+            o[k] = tab[v];
+            bad |= (unsigned)(v >= 256) & (unsigned)(v < min_ok);
+          }
+          if (bad) { e = "inflate failed: invalid distance too far back"; return false; }
+          expected = c->end_bit;
+          ended = c->ended;
+          par.release_upto(++i);
+          ++n_par;
+          b_par += blk.data.size();
+          if (!deliver(blk)) return false;
+          continue;
+        }
+        ++i;  // decode error behind a confirmed start: the serial decode below reports it (or gets past a decoder limit)
+      }
+      // serial stretch from the confirmed position to the next detected start beyond it (an unconfirmed start, a
+      // chunk that stopped early, a stream in which no start was found): streamed in blocks like the serial path
+      int j = i;
+      while (j < n && (par.start_of(j) <= expected || par.start_of(j) >= par.start_of(j + 1))) ++j;
+      const uint64_t stop = j < n ? par.start_of(j) : dcio::FastInflate::NO_STOP;
+      ++n_ser;
+      if (!seq) seq.reset(new dcio::FastInflate);
+      if (!seq->seek_bit(q, expected, fend)) { e = "unexpected end of gzip stream"; return false; }
+      const size_t cap = kBlock;
+      std::vector<uint8_t> rb(32768 + cap + dcio::FastInflate::SLACK + 16);
+      size_t w = win.size();
+      if (w) memcpy(rb.data() + 32768 - w, win.data(), w);
+      uint8_t* o = rb.data() + 32768;
+      for (;;) {
+        const size_t before = (size_t)(o - (rb.data() + 32768));
+        const dcio::FastInflate::Status st = seq->run_t<uint8_t>(o, rb.data() + 32768 + cap, (uint64_t)(w + before), stop);
+        const size_t have = (size_t)(o - (rb.data() + 32768));
+        if (st == dcio::FastInflate::NEED_OUTPUT) {
+          if (cancelled()) return true;
+          Block blk;
+          blk.data.assign(rb.data() + 32768, rb.data() + 32768 + have);
+          b_ser += have;
+          if (!deliver(blk)) return false;
+          memmove(rb.data(), rb.data() + have, 32768);  // have >= cap >= 32 KiB: the last 32 KiB become the history
+          w = 32768;
+          o = rb.data() + 32768;
+          continue;
+        }
+        if (st == dcio::FastInflate::BLOCK_STOP || st == dcio::FastInflate::MEMBER_END) {
+          ended = st == dcio::FastInflate::MEMBER_END;
+          expected = ended ? (uint64_t)(seq->input_pos() - q) * 8 : seq->bit_pos();
+          Block blk;
+          blk.data.assign(rb.data() + 32768, rb.data() + 32768 + have);
+          b_ser += have;
+          if (!deliver(blk)) return false;
+          break;
+        }
+        e = st == dcio::FastInflate::ERR_TRUNCATED ? "unexpected end of gzip stream" : std::string("inflate failed: ") + seq->error();
+        return false;
+      }
+      i = j;
+    }
+    if (getenv("DC_IO_DEBUG"))
+      fprintf(stderr, "[dc_io] parallel inflate: %d chunks, %llu decoded by workers (%llu bytes), %llu serial stretches (%llu bytes)\n", n,
+              (unsigned long long)n_par, (unsigned long long)b_par, (unsigned long long)n_ser, (unsigned long long)b_ser);
+    return true;
+  }
+
   // gzip / BGZF through the in-house decoder (fast_inflate.h) on a memory-mapped file.  Same contract as run_gzip:
   // multi-member streams, trailing zero padding, CRC-32 and length of every member checked, BGZF range ends.
   bool run_fast() {
@@ -217,6 +535,21 @@ struct Source {
     int64_t pushed = 0;
     std::string e;
     std::vector<Mark> marks;
+    // parallel inflate of large single members: $DC_IO_INFLATE_THREADS (default 4, fewer on small hosts; 1 = off),
+    // $DC_IO_INFLATE_CHUNK compressed bytes per chunk (default 4 MiB; a member shorter than four chunks stays serial)
+    int par_threads = 4;
+    {
+      const unsigned hw = std::thread::hardware_concurrency();
+      if (hw && hw < 16) par_threads = hw >= 8 ? 2 : 1;
+      if (const char* v = getenv("DC_IO_INFLATE_THREADS")) par_threads = atoi(v);
+      if (par_threads > 32) par_threads = 32;
+    }
+    size_t par_chunk = 4u << 20;
+    if (const char* v = getenv("DC_IO_INFLATE_CHUNK")) {
+      const long c = atol(v);
+      if (c >= 4096) par_chunk = (size_t)c;
+    }
+    bool par_allowed = true;
     auto flush = [&](bool all) {  // hand over [out0, out); keep the last 32 KiB as history
       const size_t have = (size_t)(out - out0);
       if (have == 0 && marks.empty()) return;
@@ -268,11 +601,23 @@ struct Source {
         else q += 2;
       }
       if (!ok) { e = "unexpected end of gzip stream"; break; }
+      uint64_t member_out = 0;
+      bool member_done = false;
+      // ---- one large member: decode it on several threads (ParInflate above) ----
+      if (par_threads > 1 && par_allowed && !(flg & 4) && start_off <= 0 && end_off == INT64_MAX &&
+          (size_t)(fend - q) >= 4 * par_chunk) {
+        flush(true);
+        const uint8_t* trailer = nullptr;
+        if (!inflate_member_parallel(q, fend, par_threads, par_chunk, member_out, trailer, pushed, e)) break;
+        if (trailer == nullptr) break;  // cancelled
+        if ((size_t)(trailer - q) < par_chunk) par_allowed = false;  // many small members: not worth speculating again
+        p = trailer + 8;
+        consumed.store((int64_t)(p - base));
+        continue;
+      }
       inf->set_input(q, fend);
       inf->begin_member();
-      uint64_t member_out = 0;
       uint8_t* seg = out;  // start of the not yet check-summed output of this member
-      bool member_done = false;
       while (!cancelled()) {
         const dcio::FastInflate::Status st = inf->run(out, out_limit, member_out + (uint64_t)(out - seg));
         if (st == dcio::FastInflate::NEED_OUTPUT || st == dcio::FastInflate::MEMBER_END) {

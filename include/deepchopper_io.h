@@ -59,7 +59,11 @@ enum dc_fq_status {
 };
 
 /* Opens plain / gzip (incl. multi-member) / BGZF FASTQ.  Decompression runs on a helper thread that
- * stays `readahead` buffers (4 MiB each, default 4 when 0 is passed) ahead of the parser. */
+ * stays `readahead` buffers (4 MiB each, default 4 when 0 is passed) ahead of the parser.
+ * Environment: DC_IO_INFLATE=zlib selects zlib instead of the in-house DEFLATE decoder; DC_IO_INFLATE_THREADS
+ * (default 4, fewer on hosts with < 16 CPUs; 1 = off) decodes one large gzip member on several threads (exactly
+ * the serial result: every speculative chunk start is confirmed by the decode that reaches it); DC_IO_INFLATE_CHUNK
+ * = compressed bytes per chunk (default 4 MiB; members shorter than four chunks are decoded serially). */
 int dc_fq_open(const char* path, int readahead, dc_fq_reader** out);
 
 /* Byte-range shard of an UNCOMPRESSED file: yields exactly the records whose '@' line starts in

@@ -144,3 +144,105 @@ def test_inflate_rate_report(tmp_path, capsys):
     with capsys.disabled():
         print(f"\n  gzip parse rate, 1 kb reads: in-house inflate {rates['fast']:.0f} reads/s, zlib {rates['zlib']:.0f} reads/s")
     assert rates["fast"] > 0 and rates["zlib"] > 0
+
+
+# ---- parallel inflate of one large member (fastq_io.cpp ParInflate): same bytes as the serial decode ----
+def _par_env(monkeypatch, threads, chunk):
+    monkeypatch.delenv("DC_IO_INFLATE", raising=False)
+    monkeypatch.setenv("DC_IO_INFLATE_THREADS", str(threads))
+    monkeypatch.setenv("DC_IO_INFLATE_CHUNK", str(chunk))
+
+
+def _sync_flushed(text, level, every, mode):
+    """pigz-like: one member, the compressor flushed (empty stored block) every `every` bytes."""
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    out = []
+    for b0 in range(0, len(text), every):
+        out.append(co.compress(text[b0: b0 + every]))
+        out.append(co.flush(mode))
+    out.append(co.flush())
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("kind", ["random", "repetitive", "skewed"])
+def test_parallel_inflate_matches_serial_on_every_block_type(tmp_path, kind, monkeypatch):
+    rng = np.random.default_rng(100 + len(kind))
+    recs = _fastq(rng, 2500, kind)
+    text = _text(recs)
+    variants = {
+        "stored": _deflate(text, 0, zlib.Z_DEFAULT_STRATEGY),           # no dynamic block anywhere: serial stretches only
+        "fixed": _deflate(text, 6, zlib.Z_FIXED),
+        "dynamic1": _deflate(text, 1, zlib.Z_DEFAULT_STRATEGY),
+        "dynamic6": _deflate(text, 6, zlib.Z_DEFAULT_STRATEGY),
+        "dynamic9_mem1": _deflate(text, 9, zlib.Z_DEFAULT_STRATEGY, mem=1),  # a block every ~250 symbols
+        "huffman_only": _deflate(text, 6, zlib.Z_HUFFMAN_ONLY),
+        "sync_flush": _sync_flushed(text, 6, 50_000, zlib.Z_SYNC_FLUSH),
+        "full_flush": _sync_flushed(text, 4, 131_072, zlib.Z_FULL_FLUSH),
+    }
+    third = len(recs) // 3
+    parts = [_text(recs[:third]), b"", _text(recs[third: 2 * third]), _text(recs[2 * third:])]
+    variants["multi_member"] = b"".join(gzip.compress(p, 6) for p in parts) + b"\0" * 11
+    for name, blob in variants.items():
+        path = str(tmp_path / f"{kind}_{name}.fq.gz")
+        open(path, "wb").write(blob)
+        _par_env(monkeypatch, 1, 16384)
+        want = _read_all(path)
+        assert sum(len(g[3]) - 1 for g in want) == len(recs), name
+        for threads, chunk in ((3, 16384), (4, 4096), (2, 100_000)):
+            _par_env(monkeypatch, threads, chunk)
+            assert _read_all(path) == want, (name, threads, chunk)
+
+
+def test_parallel_inflate_non_text_literals_and_errors(tmp_path, monkeypatch):
+    rng = np.random.default_rng(11)
+    # header comments with bytes outside the text range: blocks holding them fail the block-start probe, so the
+    # coordinator has to bridge them serially; the result must not change
+    recs = []
+    for i in range(3000):
+        L = int(rng.integers(200, 1500))
+        junk = bytes(rng.integers(128, 256, int(rng.integers(0, 40))).astype(np.uint8)) if i % 3 == 0 else b""
+        recs.append((b"r%d " % i + junk, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L)),
+                     bytes(rng.integers(33, 127, L).astype(np.uint8))))
+    text = _text(recs)
+    blob = gzip.compress(text, 6)
+    p = str(tmp_path / "junk.fq.gz")
+    open(p, "wb").write(blob)
+    _par_env(monkeypatch, 1, 16384)
+    want = _read_all(p)
+    _par_env(monkeypatch, 4, 16384)
+    assert _read_all(p) == want
+    # corruption and truncation are still reported in parallel mode
+    cases = {"truncated": blob[: len(blob) // 2], "no_trailer": blob[:-5]}
+    for frac in (0.1, 0.5, 0.9):
+        bad = bytearray(blob)
+        bad[int(len(bad) * frac)] ^= 0x55
+        cases[f"bit_flip_{frac}"] = bytes(bad)
+    crc = bytearray(blob)
+    crc[-6] ^= 1
+    cases["bad_crc"] = bytes(crc)
+    isz = bytearray(blob)
+    isz[-2] ^= 1
+    cases["bad_isize"] = bytes(isz)
+    for name, b in cases.items():
+        pb = str(tmp_path / f"{name}.fq.gz")
+        open(pb, "wb").write(b)
+        with pytest.raises((RuntimeError, ValueError)):
+            _read_all(pb)
+
+
+def test_parallel_inflate_huge_expansion_is_bounded(tmp_path, monkeypatch):
+    """A few hundred KB that inflate to > 100 MB: workers stop at their symbol budget, the rest streams serially."""
+    unit = b"@r\n" + b"ACGT" * 250 + b"\n+\n" + b"I" * 1000 + b"\n"
+    n = 60_000
+    p = str(tmp_path / "rep.fq.gz")
+    with gzip.open(p, "wb", compresslevel=6) as fh:
+        for _ in range(60):
+            fh.write(unit * (n // 60))
+    assert os.path.getsize(p) < (2 << 20)
+    _par_env(monkeypatch, 3, 16384)
+    got = 0
+    with FastqReader(p) as rd:
+        for c in rd.chunks(8192, 16 << 20):
+            got += c.n
+            assert c.seq[:8].tobytes() == b"ACGTACGT"
+    assert got == n
