@@ -385,6 +385,19 @@ struct Source {
     finish(e);
   }
 
+  // The memory-mapped input counts towards the process's resident set as it is touched: pages behind the decoder are
+  // handed back every 16 MiB so that a multi-GB file does not show up as multi-GB of RSS.
+  const uint8_t* map_base_ = nullptr;
+  size_t map_dropped_ = 0;
+  void drop_input_behind(const uint8_t* pos) {
+    if (!map_base_ || pos <= map_base_) return;
+    const size_t upto = ((size_t)(pos - map_base_)) & ~(size_t)4095;
+    if (upto >= map_dropped_ + (16u << 20)) {
+      madvise((void*)(map_base_ + map_dropped_), upto - map_dropped_, MADV_DONTNEED);
+      map_dropped_ = upto;
+    }
+  }
+
   static void append_window(std::vector<uint8_t>& win, const uint8_t* d, size_t n) {
     constexpr size_t W = 32768;
     if (n >= W) {
@@ -423,6 +436,7 @@ struct Source {
       pushed += (int64_t)blk.data.size();
       if (ended && !finish_member(blk)) return false;
       push(std::move(blk));
+      drop_input_behind(q + (expected >> 3));  // workers only run ahead of the confirmed position
       return true;
     };
     const int n = par.n_chunks();
@@ -523,6 +537,8 @@ struct Source {
     madvise(map, fsize, MADV_SEQUENTIAL);
     fast_crc.store(true);
     const uint8_t* const base = (const uint8_t*)map;
+    map_base_ = base;
+    map_dropped_ = 0;
     const uint8_t* p = base + (start_off > 0 && (size_t)start_off < fsize ? (size_t)start_off : 0);
     if (start_off >= (int64_t)fsize) p = base + fsize;
     const uint8_t* const fend = base + fsize;
@@ -624,6 +640,7 @@ struct Source {
           member_out += (uint64_t)(out - seg);
           if (st == dcio::FastInflate::MEMBER_END) { member_done = true; break; }
           flush(false);
+          drop_input_behind(inf->input_pos() - 16);
           seg = out;
           continue;
         }
