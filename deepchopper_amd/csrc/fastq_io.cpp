@@ -122,20 +122,30 @@ class ParInflate {
     if (i > released_) released_ = i;
     cv_.notify_all();
   }
-  // first detected block start at or after chunk j's byte offset (memoised; total_bits = none before the end)
+  // first detected block start at or after chunk j's byte offset, searched over at most two chunk lengths (blocks are
+  // tens of KB apart: nothing within 8 MiB means stored / fixed-Huffman / non-text data, which is decoded serially);
+  // memoised.  total_bits = none found.
   uint64_t start_of(int j) {
     if (j <= 0) return 0;
     if (j >= n_) return total_bits_;
     {
       std::unique_lock<std::mutex> lk(mu_);
       cv_.wait(lk, [&] { return start_state_[(size_t)j] != 1 || stop_; });
-      if (start_state_[(size_t)j] == 2 || stop_) return starts_[(size_t)j];
+      if (start_state_[(size_t)j] == 2 || stop_) return start_state_[(size_t)j] == 2 ? starts_[(size_t)j] : total_bits_;
       start_state_[(size_t)j] = 1;
     }
-    const uint64_t s = scan((uint64_t)j * chunk_bytes_ * 8);
+    const uint64_t from = (uint64_t)j * chunk_bytes_ * 8;
+    const uint64_t s = scan(from, from + 2 * (uint64_t)chunk_bytes_ * 8);
     std::lock_guard<std::mutex> lk(mu_);
     starts_[(size_t)j] = s;
     start_state_[(size_t)j] = 2;
+    // the first start at or after offset j is also the first one for every later chunk whose offset it lies behind
+    for (int k = j + 1; k < n_ && s < total_bits_ && (uint64_t)k * chunk_bytes_ * 8 <= s; ++k) {
+      if (start_state_[(size_t)k] == 0) {
+        starts_[(size_t)k] = s;
+        start_state_[(size_t)k] = 2;
+      }
+    }
     cv_.notify_all();
     return s;
   }
@@ -161,11 +171,12 @@ class ParInflate {
     memcpy(&v, p, 8);
     return v;
   }
-  uint64_t scan(uint64_t from_bit) {
+  uint64_t scan(uint64_t from_bit, uint64_t limit_bit) {
     std::unique_ptr<dcio::FastInflate> probe(new dcio::FastInflate);
     std::vector<uint16_t> scratch(32768 + TRIAL + dcio::FastInflate::SLACK + 16);
     // a header needs 17 bits + up to 19 x 3: stop while 16 readable bytes remain (the tail belongs to the previous chunk)
-    const uint64_t last = total_bits_ > 160 ? total_bits_ - 160 : 0;
+    uint64_t last = total_bits_ > 160 ? total_bits_ - 160 : 0;
+    if (limit_bit < last) last = limit_bit;
     unsigned tick = 0;
     for (uint64_t p = from_bit; p < last; ++p) {
       const uint8_t* b8 = origin_ + (p >> 3);

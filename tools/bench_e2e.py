@@ -92,10 +92,15 @@ def chop_bench(args):
         os.remove(final)
         os.remove(warm)
         torch.cuda.synchronize()
+        if os.environ.get("DC_PROFILE_STAGES"):  # GPU time per stage next to the wall time: is the flow GPU-bound?
+            pipe.model.net.set_profiling(True)
+            pipe.model.net.profile_reset()
         t0 = time.time()
         final, n_reads, n_out = predict_chop(path, pipe, threads=args.threads, max_reads=args.max_reads, max_tokens=args.max_tokens)
         torch.cuda.synchronize()
         dt = time.time() - t0
+        if os.environ.get("DC_PROFILE_STAGES"):
+            out["stages_ms"] = {k: round(v[0], 1) for k, v in pipe.model.net.profile().items()}
         rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
     else:
         cmd = [sys.executable, "-m", "deepchopper_amd.cli", "predict", path, "-g", str(args.gpus), "--chop", "-m", ckpt,
