@@ -2237,6 +2237,11 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
   };
   auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
     l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef DC_H3_ABL_NOZLOAD  // ablation: the tile's inputs come from registers, not from memory (wrong results)
+    l1.x = c1.x = __builtin_bit_cast(float, (uint32_t)(0x01020300u + (p & 3)));
+    lv.y = cv.z = (float)p;
+    return;
+#endif
     if (TAB) {  // the token ids of positions t-4 .. t+3 travel in l1.x / c1.x; z_store looks the values up
       uint32_t il = 0xFFFFFFFFu, ic = 0xFFFFFFFFu;
       if (p < z_nblk) {
@@ -2277,7 +2282,14 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
     // split of 4 values (padded to the 8-wide splitter) -> NP 8-byte stores
     const float z8[8] = {z[0], z[1], z[2], z[3], 0.f, 0.f, 0.f, 0.f};
     svec pl8[NP];
+#ifdef DC_H3_ABL_NOZSPLIT  // ablation: conversion only, no residual planes / range check (wrong results)
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pl8[q][j] = (decltype(pl8[q][j] + pl8[q][j]))z8[j];
+#else
     ovf = ovf || SM::split(z8, pl8);
+#endif
     unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (zr * H3_ZROW + zq4) * 2;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -2352,7 +2364,11 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
 
     for (int p = p_in0; p <= p_in_last; ++p) {
       float4 l1, c1, lv, cv;
+#ifdef DC_H3_ABL_NOZ  // ablation: z tiles are not produced inside the loop (wrong results)
+      const bool more = false;
+#else
       const bool more = p < p_in_last;
+#endif
       if (more) z_load(p + 1, l1, c1, lv, cv);
 
       // A (data) fragments: z[read r32][16 s + 8 h .. +7] of the three planes
@@ -2373,7 +2389,14 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
 #pragma unroll
           for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
+            for (int pl = 0; pl < NP; ++pl) {
+#ifdef DC_H3_ABL_NOFK  // ablation: no filter-fragment LDS reads (wrong results)
+              fk[s][pl] = za[s][pl];
+              (void)fb;
+#else
+              fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
+#endif
+            }
           f32x16 cacc = acc[m];
 #pragma unroll
           for (int s = 0; s < 2; ++s) cacc = SM::mma(za[s], fk[s], cacc);
@@ -2381,7 +2404,9 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
         }
       }
       if (more) z_store(p + 1, l1, c1, lv, cv);
+#ifndef DC_H3_ABL_NOBAR  // ablation: no barrier per input tile (wrong results)
       __syncthreads();
+#endif
     }
   }
 
