@@ -2188,7 +2188,7 @@ template <int CB, int MODE, bool TAB>  // CB: blocks per output chunk, 32 (reads
 #ifndef DC_H3_OCC
 #define DC_H3_OCC 2
 #endif
-__global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
+__global__ __launch_bounds__(256, CB == 16 ? 3 : DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {  // CB 16: 64 accumulator registers, three waves per SIMD fit (<= 168 VGPRs) and are worth 9 %
   typedef SplitMode<MODE> SM;
   typedef typename SM::vec svec;
   constexpr int NP = SM::NP;
@@ -2262,6 +2262,45 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
       c1 = *reinterpret_cast<const float4*>(ux1 + t);
       cv = *reinterpret_cast<const float4*>(uv + t);
     }
+  };
+  // Inside the tile loop only the current four tokens are loaded: the two tokens in front of them are the last two of
+  // the lane below (same read: eight lanes per read row, inside one DPP row of 16), and for a read's first lane the
+  // last two of its eighth lane in the PREVIOUS tile, remembered in `tail`.  Halves the load instructions of the
+  // loop (the re-fetched quads hit L1/L2 but cost address-path bandwidth, profiles/r02_hyena3_ablations.json).
+  float4 tail = make_float4(0.f, 0.f, 0.f, 0.f);  // x1[t+2], x1[t+3], v[t+2], v[t+3] of the lane's last tile (TAB: .x = ids)
+  auto z_load_cur = [&](int p, float4& c1, float4& cv) {
+    c1 = cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TAB) {
+      uint32_t ic = 0xFFFFFFFFu;
+      if (p < z_nblk) ic = *reinterpret_cast<const uint32_t*>(tkz + 32 * p + zq4);
+      c1.x = __builtin_bit_cast(float, ic);
+      return;
+    }
+    if (p < z_nblk) {
+      const int64_t t = 32 * p + zq4;
+      c1 = *reinterpret_cast<const float4*>(ux1 + t);
+      cv = *reinterpret_cast<const float4*>(uv + t);
+    }
+  };
+  auto from_below = [&](float own, float carried) -> float {  // row_shr:1 / row_shl:7 of a DPP row of 16 lanes
+    const int o = __builtin_bit_cast(int, own), k = __builtin_bit_cast(int, carried);
+    const int below = __builtin_amdgcn_update_dpp(0, o, 0x111, 0xf, 0xf, false);
+    const int wrap = __builtin_amdgcn_update_dpp(0, k, 0x107, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, (tid & 7) == 0 ? wrap : below);
+  };
+  auto neighbours = [&](const float4& c1, const float4& cv, float4& l1, float4& lv) {
+    l1 = lv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (TAB) {
+      l1.x = from_below(c1.x, tail.x);
+    } else {
+      l1.z = from_below(c1.z, tail.x);
+      l1.w = from_below(c1.w, tail.y);
+      lv.z = from_below(cv.z, tail.z);
+      lv.w = from_below(cv.w, tail.w);
+    }
+  };
+  auto keep_tail = [&](const float4& c1, const float4& cv) {
+    tail = TAB ? make_float4(c1.x, 0.f, 0.f, 0.f) : make_float4(c1.z, c1.w, cv.z, cv.w);
   };
   bool ovf = false;  // fp16x3: a z value left the fp16 range
   auto z_store = [&](int p, const float4& l1_, const float4& c1_, const float4& lv_, const float4& cv_) {
@@ -2356,6 +2395,7 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
       float4 l1, c1, lv, cv;
       z_load(p_in0, l1, c1, lv, cv);
       z_store(p_in0, l1, c1, lv, cv);
+      keep_tail(c1, cv);
     }
     __syncthreads();
 #ifdef DC_STAMP
@@ -2369,7 +2409,11 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
 #else
       const bool more = p < p_in_last;
 #endif
+#ifdef DC_H3_FULL_LOADS  // A/B: every thread also loads the four tokens in front of its own
       if (more) z_load(p + 1, l1, c1, lv, cv);
+#else
+      if (more) z_load_cur(p + 1, c1, cv);
+#endif
 
       // A (data) fragments: z[read r32][16 s + 8 h .. +7] of the three planes
       const unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (r32 * H3_ZROW + 8 * h) * 2;
@@ -2403,7 +2447,13 @@ __global__ __launch_bounds__(256, DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {
           acc[m] = cacc;
         }
       }
-      if (more) z_store(p + 1, l1, c1, lv, cv);
+      if (more) {
+#ifndef DC_H3_FULL_LOADS
+        neighbours(c1, cv, l1, lv);
+#endif
+        z_store(p + 1, l1, c1, lv, cv);
+        keep_tail(c1, cv);
+      }
 #ifndef DC_H3_ABL_NOBAR  // ablation: no barrier per input tile (wrong results)
       __syncthreads();
 #endif
