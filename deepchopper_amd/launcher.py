@@ -246,7 +246,10 @@ class ChunkFeeder:
                         return
                     write_chunk(fh, c)
         except BrokenPipeError:
-            pass  # the worker died; wait_ranks reports it
+            # the worker died (wait_ranks reports it): keep taking its share off the queue so that the reader thread,
+            # which deals round-robin through bounded queues, is not left blocked on this one
+            while self._queues[i].get() is not None:
+                pass
         except BaseException as e:
             self.error = self.error or e
 
