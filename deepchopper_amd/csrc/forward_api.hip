@@ -65,7 +65,7 @@ struct dc_model {
   int64_t kf_taps = 0;
   float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
   bool kspec_valid[5] = {false, false, false, false, false};  // spectra match the materialised filters
-  int fft_min_tokens = 3072;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
+  int fft_min_tokens = 2560;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
   // FFT buckets of the cached geometry: read lists by transform size
   int32_t* d_fft_reads = nullptr;
   int fft_count[5] = {0, 0, 0, 0, 0}, fft_offset[5] = {0, 0, 0, 0, 0};

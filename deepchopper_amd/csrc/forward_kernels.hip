@@ -2188,7 +2188,10 @@ template <int CB, int MODE, bool TAB>  // CB: blocks per output chunk, 32 (reads
 #ifndef DC_H3_OCC
 #define DC_H3_OCC 2
 #endif
-__global__ __launch_bounds__(256, CB == 16 ? 3 : DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {  // CB 16: 64 accumulator registers, three waves per SIMD fit (<= 168 VGPRs) and are worth 9 %
+#ifndef DC_H3_OCC16
+#define DC_H3_OCC16 3
+#endif
+__global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena3_kernel(HyenaArgs a) {  // CB 16: 64 accumulator registers, three waves per SIMD fit (<= 168 VGPRs) and are worth 9 %
   typedef SplitMode<MODE> SM;
   typedef typename SM::vec svec;
   constexpr int NP = SM::NP;

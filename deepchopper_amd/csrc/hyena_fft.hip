@@ -36,6 +36,16 @@ __global__ __launch_bounds__(256) void fft_twiddle_kernel(float2* __restrict__ t
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
+// two-lane fp32 vectors: the pointwise phases are written on these so that they compile to v_pk_* instructions
+// (left as scalar float2 code the SLP vectoriser packed the butterflies but none of the pointwise loops)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f V(float2 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ float2 F(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vcmul(v2f a, v2f b) {  // complex product
+  return vfma(v2f{-a.y, a.y}, b.yx, a.xx * b);
+}
+__device__ __forceinline__ v2f vconj(v2f a) { return v2f{a.x, -a.y}; }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
@@ -85,17 +95,17 @@ __device__ __forceinline__ void dft_regs(float2 (&u)[R]) {
 
 __device__ __forceinline__ int pad16(int idx) { return idx + (idx >> 4); }
 
-// One Stockham pass of radix R over the M points in LDS; p = product of the radices of the passes before it.
-// T = M / 16 threads; every thread owns 16 / R butterflies.  Loads of all threads precede all stores (two
-// barriers), so the pass runs in place.
+// Twiddles of one pass for one thread: w = exp(-2 pi i k / (p R)) for its NB butterflies, as w, w^2, w^4, w^8 (the
+// other powers are at most three products away).  They come from the exact table in global memory (L2): a pass
+// requests the twiddles of the NEXT pass before it starts its own work, so their round trip (several hundred cycles,
+// longer than a pass's LDS reads + barrier) is hidden behind a whole pass instead of parking every wave once per pass.
 template <int LOGM, int R>
-__device__ __forceinline__ void fft_pass(float2* __restrict__ s, const float2* __restrict__ tw, int p, int tid) {
-  constexpr int M = 1 << LOGM, T = M / 16, NB = 16 / R, LOGR = ilog2(R);
-  float2 u[NB][R];
-  // twiddle lookups first: their L2 round trip overlaps the LDS reads and the barrier.
-  // w = exp(-2 pi i k / (p R)); w^t for t < R comes from w, w^2, w^4, w^8 and at most three products.
+struct PassTw {
+  static constexpr int NB = 16 / R;
   float2 w1[NB], w2[NB], w4[NB], w8[NB];
-  if (p > 1) {
+  __device__ __forceinline__ void load(const float2* __restrict__ tw, int p, int tid) {
+    constexpr int T = (1 << LOGM) / 16;
+    if (p <= 1) return;
     const int step = FFT_TW_N / (p * R);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -106,6 +116,15 @@ __device__ __forceinline__ void fft_pass(float2* __restrict__ s, const float2* _
       if (R > 8) w8[b] = tw[(8 * k * step) & (FFT_TW_N - 1)];
     }
   }
+};
+
+// One Stockham pass of radix R over the M points in LDS; p = product of the radices of the passes before it.
+// T = M / 16 threads; every thread owns 16 / R butterflies.  Loads of all threads precede all stores (two
+// barriers), so the pass runs in place.  `w` holds this pass's twiddles (requested during the previous pass).
+template <int LOGM, int R>
+__device__ __forceinline__ void fft_pass(float2* __restrict__ s, const PassTw<LOGM, R>& w, int p, int tid) {
+  constexpr int M = 1 << LOGM, T = M / 16, NB = 16 / R, LOGR = ilog2(R);
+  float2 u[NB][R];
   // M / R and b T are multiples of 16, so the pad of a point is that of (tid) plus a constant: one base address,
   // immediate offsets
   const float2* sr = s + pad16(tid);
@@ -124,10 +143,10 @@ __device__ __forceinline__ void fft_pass(float2* __restrict__ s, const float2* _
     const int k = i & (p - 1);
     if (p > 1) {
       float2 wp[16];
-      wp[1] = w1[b];
-      if (R > 2) wp[2] = w2[b];
-      if (R > 4) wp[4] = w4[b];
-      if (R > 8) wp[8] = w8[b];
+      wp[1] = w.w1[b];
+      if (R > 2) wp[2] = w.w2[b];
+      if (R > 4) wp[4] = w.w4[b];
+      if (R > 8) wp[8] = w.w8[b];
 #pragma unroll
       for (int t = 3; t < R; ++t) {
         if ((t & (t - 1)) != 0) {  // not a power of two: highest set bit times the rest
@@ -155,17 +174,22 @@ __device__ __forceinline__ void fft_pass(float2* __restrict__ s, const float2* _
 
 template <int LOGM>
 __device__ __forceinline__ void fft_lds(float2* __restrict__ s, const float2* __restrict__ tw, int tid) {
-  // radices: 16 while they fit, then the rest (2, 4 or 8)
-  fft_pass<LOGM, 16>(s, tw, 1, tid);
-  fft_pass<LOGM, 16>(s, tw, 16, tid);
-  if constexpr (LOGM == 10) {
-    fft_pass<LOGM, 4>(s, tw, 256, tid);
-  } else if constexpr (LOGM == 11) {
-    fft_pass<LOGM, 8>(s, tw, 256, tid);
+  // radices: 16 while they fit, then the rest (2, 4 or 8).  Twiddle requests run one pass ahead.
+  constexpr int R3 = LOGM == 10 ? 4 : LOGM == 11 ? 8 : 16;   // third pass
+  constexpr int R4 = LOGM == 13 ? 2 : LOGM == 14 ? 4 : 0;    // fourth pass (2^13, 2^14 only)
+  PassTw<LOGM, 16> w1, w2;
+  PassTw<LOGM, R3> w3;
+  w2.load(tw, 16, tid);
+  fft_pass<LOGM, 16>(s, w1, 1, tid);
+  w3.load(tw, 256, tid);
+  fft_pass<LOGM, 16>(s, w2, 16, tid);
+  if constexpr (R4 != 0) {
+    PassTw<LOGM, R4> w4;
+    w4.load(tw, 4096, tid);
+    fft_pass<LOGM, R3>(s, w3, 256, tid);
+    fft_pass<LOGM, R4>(s, w4, 4096, tid);
   } else {
-    fft_pass<LOGM, 16>(s, tw, 256, tid);
-    if constexpr (LOGM == 13) fft_pass<LOGM, 2>(s, tw, 4096, tid);
-    if constexpr (LOGM == 14) fft_pass<LOGM, 4>(s, tw, 4096, tid);
+    fft_pass<LOGM, R3>(s, w3, 256, tid);
   }
 }
 
@@ -242,94 +266,167 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
     __syncthreads();
   }
   // short causal filter (order 3, weight index 0 = oldest tap) of row group k3 (0 x0, 1 x1, 2 v) at tokens t, t + 1
-  // (t even): four consecutive values u[t-2 .. t+1] as two aligned 8-byte loads (reads start at multiples of 32
-  // tokens; slots between L and the end of the read's last 32-block are readable and masked here)
-  auto short2 = [&](int k3, const float* row, int t, float& o0, float& o1) {
-    const float w0 = a.sw[(k3 * D + c) * 3 + 0], w1 = a.sw[(k3 * D + c) * 3 + 1], w2 = a.sw[(k3 * D + c) * 3 + 2],
-                b = a.sb[k3 * D + c];
-    float um2 = 0.f, um1 = 0.f, u0, u1;
+  // (t even).  Loading and evaluating are separate steps: every pointwise loop below first issues the loads of UB
+  // iterations and only then consumes them -- written as one load-then-use body per iteration, each iteration paid a
+  // full memory round trip (16 + 8 + 16 of them in sequence were ~80 % of a workgroup's life).
+  //   non-TAB: u[t-2 .. t+1] as two aligned 8-byte loads (reads start at multiples of 32 tokens; slots between L and
+  //            the end of the read's last 32-block are readable and masked here)
+  //   TAB:     the four token ids as two 16-bit loads; values from the 17-entry table in LDS (0xFF -> entry 16 = 0)
+  struct Raw {
+    float2 lo, hi;  // non-TAB: u[t-2], u[t-1] | u[t], u[t+1].   TAB: lo.x carries the four ids
+  };
+  // Branch-free: the addresses are clamped into the read and the values masked afterwards -- a load inside a
+  // divergent branch is followed by its own s_waitcnt vmcnt(0), which would serialise the batch again.
+  const int t_last = L > 0 ? (L - 1) & ~1 : 0;  // last even token position of the read
+  auto raw_load = [&](const float* row, int t) -> Raw {
+    Raw r;
+    const int tc = t < t_last ? t : t_last;
+    const int tl = tc >= 2 ? tc - 2 : 0;
     if (TAB) {
-      auto val = [&](int tt) -> float {
-        if (tt < 0 || tt >= L) return 0.f;
-        const unsigned id = tok[tt];
+      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + tc);
+      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + tl);
+      uint32_t ids = (t >= 2 ? lo16 : 0xFFFFu) | (hi16 << 16);
+      if (t + 1 >= L) ids |= 0xFF000000u;
+      if (t >= L) ids = 0xFFFFFFFFu;
+      r.lo = make_float2(__builtin_bit_cast(float, ids), 0.f);
+      r.hi = make_float2(0.f, 0.f);
+      return r;
+    }
+    const float2 lo = *reinterpret_cast<const float2*>(row + tl);
+    const float2 hi = *reinterpret_cast<const float2*>(row + tc);
+    const bool in = t < L;
+    r.lo = make_float2(in && t >= 2 ? lo.x : 0.f, in && t >= 2 ? lo.y : 0.f);
+    r.hi = make_float2(in ? hi.x : 0.f, in && t + 1 < L ? hi.y : 0.f);
+    return r;
+  };
+  float sw_[3][3], sb_[3];
+#pragma unroll
+  for (int k3 = 0; k3 < 3; ++k3) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sw_[k3][j] = a.sw[(k3 * D + c) * 3 + j];
+    sb_[k3] = a.sb[k3 * D + c];
+  }
+  auto sc_eval = [&](int k3, const Raw& r) -> v2f {  // the filter's outputs at t, t + 1
+    v2f lo, hi;
+    if (TAB) {
+      const uint32_t ids = __builtin_bit_cast(uint32_t, r.lo.x);
+      auto val = [&](int byte) -> float {
+        const uint32_t id = (ids >> (8 * byte)) & 255u;
         return s_tab[k3 * 17 + (id < 16u ? id : 16u)];
       };
-      um2 = val(t - 2);
-      um1 = val(t - 1);
-      u0 = val(t);
-      u1 = val(t + 1);
+      lo = v2f{val(0), val(1)};
+      hi = v2f{val(2), val(3)};
     } else {
-      if (t >= 2) {
-        const float2 lo = *reinterpret_cast<const float2*>(row + t - 2);
-        um2 = lo.x;
-        um1 = lo.y;
-      }
-      const float2 hi = *reinterpret_cast<const float2*>(row + t);
-      u0 = hi.x;
-      u1 = t + 1 < L ? hi.y : 0.f;
+      lo = V(r.lo);
+      hi = V(r.hi);
     }
-    o0 = fmaf(w0, um2, fmaf(w1, um1, fmaf(w2, u0, b)));
-    o1 = fmaf(w0, um1, fmaf(w1, u0, fmaf(w2, u1, b)));
+    const v2f mid = v2f{lo.y, hi.x};
+    const v2f w0 = sw_[k3][0], w1 = sw_[k3][1], w2 = sw_[k3][2], bb = sb_[k3];  // splats
+    return vfma(w0, lo, vfma(w1, mid, vfma(w2, hi, bb)));
   };
+  constexpr int NIT = M / T;  // 16 points per thread
+  constexpr int UB = 4;       // iterations whose loads are in flight together
+  constexpr int PSTEP = T + T / 16;  // pad16(tid + j T) = pad16(tid) + j PSTEP (T is a multiple of 16)
+  float2* const s_me = s + pad16(tid);
 
   // ---- gated input, packed: c[m] = z[2m] + i z[2m+1] ----
-  for (int m = tid; m < M; m += T) {
-    const int t = 2 * m;
-    float2 z = make_float2(0.f, 0.f);
-    if (t < L) {
-      float a0, a1, b0, b1;
-      short2(1, ux1, t, a0, a1);
-      short2(2, uv, t, b0, b1);
-      z.x = a0 * b0;
-      z.y = t + 1 < L ? a1 * b1 : 0.f;
+#pragma unroll 1
+  for (int j0 = 0; j0 < NIT; j0 += UB) {
+    if (2 * (j0 * T) >= L) {  // block-uniform: this batch lies in the zero padding (at least half of the M points do)
+#pragma unroll
+      for (int u = 0; u < UB; ++u) s_me[(j0 + u) * PSTEP] = make_float2(0.f, 0.f);
+      continue;
     }
-    s[pad16(m)] = z;
+    Raw r1[UB], rv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int t = 2 * (tid + (j0 + u) * T);
+      r1[u] = raw_load(ux1, t);
+      if (!TAB) rv[u] = raw_load(uv, t);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int t = 2 * (tid + (j0 + u) * T);
+      v2f z = sc_eval(1, r1[u]) * sc_eval(2, TAB ? r1[u] : rv[u]);
+      if (t >= L) z = v2f{0.f, 0.f};
+      else if (t + 1 >= L) z.y = 0.f;
+      s_me[(j0 + u) * PSTEP] = F(z);
+    }
   }
   __syncthreads();
   fft_lds<LOGM>(s, tw, tid);
 
   // ---- spectrum product and repacking for the inverse transform (stored conjugated: IFFT = conj . FFT . conj) ----
   const float2* K = spec + (int64_t)c * (M + 1);
-  for (int kk = tid; kk <= M / 2; kk += T) {
-    const float2 ck = s[pad16(kk)], cmk = s[pad16((M - kk) & (M - 1))];
-    const float2 wk = tw[kk * (FFT_TW_N / (2 * M))];
-    float2 yk, ymk;
+  constexpr int TWS = FFT_TW_N / (2 * M);
+  auto product = [&](int kk, float2 kf_, float2 kb_, float2 wk_) {  // kf = K[kk], kb = K[M - kk]
+    const v2f ck = V(s[pad16(kk)]), cmk = V(s[pad16((M - kk) & (M - 1))]);
+    const v2f kf = V(kf_), kb = V(kb_), wk = V(wk_);
     if (kk == 0) {
-      const float2 k0 = K[0], kn = K[M];
-      yk = make_float2((ck.x + ck.y) * k0.x, 0.f);   // Y[0]  (real)
-      ymk = make_float2((ck.x - ck.y) * kn.x, 0.f);  // Y[M]  (real)
-      // Ye[0] = (Y[0] + Y[M]) / 2, Yo[0] = (Y[0] - Y[M]) / 2; C'[0] = Ye + i Yo
-      s[pad16(0)] = make_float2(0.5f * (yk.x + ymk.x), -0.5f * (yk.x - ymk.x));  // conj(C'[0])
-    } else {
-      float2 zk, zmk;
-      unpack_pair<LOGM>(ck, cmk, wk, zk, zmk);
-      yk = cmul(zk, K[kk]);
-      ymk = cmul(zmk, K[M - kk]);
-      // Ye[k] = (Y[k] + conj(Y[M-k])) / 2,  Yo[k] = conj(W^k) (Y[k] - conj(Y[M-k])) / 2
-      const float2 b = cconj(ymk);
-      const float2 ye = make_float2(0.5f * (yk.x + b.x), 0.5f * (yk.y + b.y));
-      const float2 d = make_float2(0.5f * (yk.x - b.x), 0.5f * (yk.y - b.y));
-      const float2 yo = cmul(cconj(wk), d);
-      // C'[k] = Ye + i Yo ;  C'[M-k] = conj(Ye) + i conj(Yo)
-      const float2 cp = make_float2(ye.x - yo.y, ye.y + yo.x);
-      const float2 cq = make_float2(ye.x + yo.y, -ye.y + yo.x);
-      s[pad16(kk)] = cconj(cp);
-      if (kk != M / 2) s[pad16(M - kk)] = cconj(cq);
+      const float y0 = (ck.x + ck.y) * kf.x;   // Y[0]  (real)
+      const float ym = (ck.x - ck.y) * kb.x;   // Y[M]  (real)
+      // Ye[0] = (Y[0] + Y[M]) / 2, Yo[0] = (Y[0] - Y[M]) / 2; C'[0] = Ye + i Yo, stored conjugated
+      s[pad16(0)] = make_float2(0.5f * (y0 + ym), -0.5f * (y0 - ym));
+      return;
     }
+    // unpack: Z[k] = E + W^k O, Z[M-k] = conj(E - W^k O), E = (C[k] + conj(C[M-k])) / 2, O = -i (C[k] - conj(C[M-k])) / 2
+    const v2f half = 0.5f;
+    const v2f bc = vconj(cmk);
+    const v2f e = half * (ck + bc), d = half * (ck - bc);
+    const v2f wo = vcmul(wk, v2f{d.y, -d.x});
+    const v2f zk = e + wo, zmk = vconj(e - wo);
+    const v2f yk = vcmul(zk, kf), ymk = vcmul(zmk, kb);
+    // repack: Ye[k] = (Y[k] + conj(Y[M-k])) / 2,  Yo[k] = conj(W^k) (Y[k] - conj(Y[M-k])) / 2
+    const v2f bq = vconj(ymk);
+    const v2f ye = half * (yk + bq), d2 = half * (yk - bq);
+    const v2f yo = vcmul(vconj(wk), d2);
+    // C'[k] = Ye + i Yo ;  C'[M-k] = conj(Ye) + i conj(Yo); both stored conjugated
+    const v2f iyo = v2f{-yo.y, yo.x};
+    const v2f cp = ye + iyo;
+    const v2f cq = vconj(ye) + v2f{yo.y, yo.x};
+    s[pad16(kk)] = F(vconj(cp));
+    if (kk != M / 2) s[pad16(M - kk)] = F(vconj(cq));
+  };
+  // pairs (kk, M - kk) for kk = tid + j T, j < NIT / 2: touched by exactly one thread each, in place
+#pragma unroll 1
+  for (int j0 = 0; j0 < NIT / 2; j0 += UB) {
+    float2 kf[UB], kb[UB], wk[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int kk = tid + (j0 + u) * T;
+      kf[u] = K[kk];
+      kb[u] = K[M - kk];
+      wk[u] = tw[kk * TWS];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) product(tid + (j0 + u) * T, kf[u], kb[u], wk[u]);
   }
+  if (tid == 0) product(M / 2, K[M / 2], K[M / 2], tw[(M / 2) * TWS]);  // the self-paired middle bin
   __syncthreads();
   fft_lds<LOGM>(s, tw, tid);
 
   // ---- y[t] = conv[t] * shortconv(x0)[t]: conv[2m] = Re r[m] / M, conv[2m+1] = -Im r[m] / M ----
   const float inv_m = 1.0f / (float)M;
   float* y = a.y + (int64_t)c * a.Tp + toff;
-  for (int m = tid; 2 * m < L; m += T) {
-    const int t = 2 * m;
-    const float2 rv = s[pad16(m)];
-    float g0, g1;
-    short2(0, ux0, t, g0, g1);
-    y[t] = rv.x * inv_m * g0;
-    if (t + 1 < L) y[t + 1] = -rv.y * inv_m * g1;
+#pragma unroll 1
+  for (int j0 = 0; j0 < NIT; j0 += UB) {
+    if (2 * (j0 * T) >= L) break;  // block-uniform: nothing of the read is left in this batch
+    Raw r0[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) r0[u] = raw_load(ux0, 2 * (tid + (j0 + u) * T));
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int t = 2 * (tid + (j0 + u) * T);
+      const v2f rv = V(s_me[(j0 + u) * PSTEP]);
+      const v2f o = rv * v2f{inv_m, -inv_m} * sc_eval(0, r0[u]);
+      if (t < L) {
+        if (t + 1 < L) {
+          *reinterpret_cast<float2*>(y + t) = F(o);
+        } else {
+          y[t] = o.x;
+        }
+      }
+    }
   }
 }
 

@@ -332,7 +332,7 @@ class HipModel:
         self.gemm_mode = mode
 
     def set_fft_threshold(self, min_tokens: int):
-        """Reads with more than `min_tokens` tokens take the O(L log L) FFT long convolution (default 3072)."""
+        """Reads with more than `min_tokens` tokens take the O(L log L) FFT long convolution (default 2560)."""
         _lib.check(_lib.lib().dc_model_set_fft_threshold(self._h, int(min_tokens)))
 
     def set_mlp_fusion(self, level):

@@ -271,10 +271,11 @@ int dc_model_set_mlp_fusion(dc_model* m, int32_t level);
 
 /* Long convolution of the Hyena operator (the reference's `fftconv`, HF-Hub code called at
  * deepchopper/models/llm/hyena.py:34-41).  Reads of up to `min_tokens` tokens run the block-Toeplitz MFMA kernel
- * (O(L^2), measured faster below ~3k tokens); longer reads (up to 16 384 tokens) run an in-LDS radix-16 FFT
- * convolution (O(L log L), fp32 like the reference; five padded sizes 2^10 .. 2^14 complex points).  Default 3072
- * ($DC_FFT_MIN); min_tokens >= 256 (DC_ERR_ARG below); a value above the model's context length disables the
- * FFT path.  Same results within the forward's tolerance either way
+ * (O(L^2), measured faster below ~2.5k tokens); longer reads (up to 16 384 tokens) run an in-LDS radix-16 FFT
+ * convolution (O(L log L), fp32 like the reference; five padded sizes 2^10 .. 2^14 complex points).  Default 2560
+ * ($DC_FFT_MIN): inside the 2^12 bucket the FFT costs the same for every read while the Toeplitz cost grows with
+ * L^2, they cross near 2 550 tokens; min_tokens >= 256 (DC_ERR_ARG below); a value above the model's context length
+ * disables the FFT path.  Same results within the forward's tolerance either way
  * (tests/test_gpu_forward.py::test_fft_long_convolution_matches_toeplitz_and_oracle). */
 int dc_model_set_fft_threshold(dc_model* m, int32_t min_tokens);
 

@@ -37,7 +37,7 @@ for rep in range(2):
     dt = time.time() - t0
 print(json.dumps({"workload": "config 4: log-uniform 100 bp - 10 kb reads, FASTQ file -> intervals", "reads": nr,
                   "mean_bp": round(bases / n, 1), "reads_per_s": round(nr / dt), "Mbases_per_s": round(bases / dt / 1e6, 2),
-                  "fft_min_tokens": os.environ.get("DC_FFT_MIN", "3072 (default)"),
+                  "fft_min_tokens": os.environ.get("DC_FFT_MIN", "2560 (default)"),
                   "stages_ms": {k: round(v[0], 1) for k, v in pipe.model.net.profile().items()} if os.environ.get("DC_PROFILE_STAGES") else None}))
 os.remove(path)
 os.rmdir(tmp)

@@ -33,7 +33,10 @@ for k in sorted(acc, key=lambda k: -dur[k]):
             line += f"  MFMA busy {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc:5.1f} %"
     wc = a.get("SQ_WAVE_CYCLES")
     if wc:
-        for n, lab in (("SQ_WAIT_ANY", "parked"), ("SQ_WAIT_INST_ANY", "issue-stall"), ("SQ_ACTIVE_INST_VALU", "valu")):
+        for n, lab in (("SQ_WAIT_ANY", "parked"), ("SQ_WAIT_INST_ANY", "issue-stall"), ("SQ_ACTIVE_INST_VALU", "valu"),
+                       ("SQ_ACTIVE_INST_LDS", "lds-inst"), ("SQ_WAIT_INST_LDS", "wait-lds")):
             if n in a:
                 line += f"  {lab} {100 * a[n] / wc:4.1f}%"
     print(line)
+    if "SQ_LDS_BANK_CONFLICT" in a and a.get("SQ_LDS_IDX_ACTIVE"):
+        print(f"    LDS bank-conflict cycles / active cycles: {100 * a['SQ_LDS_BANK_CONFLICT'] / a['SQ_LDS_IDX_ACTIVE']:.1f} %")
