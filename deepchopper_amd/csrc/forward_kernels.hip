@@ -989,7 +989,12 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
         glds16_s(a1, voff, base + ((pl * 4 + o) * M_HC + seg * 64) * 16);
       } else {
         const int row = q - 16;
+#ifdef DC_ABL_M_XHOT  // ablation: every X tile is k-tile 0 (32 KiB per workgroup, cache resident): how much of the
+                      // kernel is the 8x re-streaming of the 256 KiB X tile through the memory system?  (wrong results)
+        glds16_s(g.X + (int64_t)row * g.Tp + t_blk, voff, base + M_A1 + row * 1024);
+#else
         glds16_s(g.X + (int64_t)(32 * s + row) * g.Tp + t_blk, voff, base + M_A1 + row * 1024);
+#endif
       }
     } else {
       const int pl = q >> 4, o = (q >> 2) & 3, seg = q & 3;
