@@ -980,6 +980,9 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   //      piece `idx` of a wave is piece number wave + 8 * idx of the tile ----
   const uint32_t voff = lane * 16;
   auto issue_one = [&](int hc, int s, int slot, int idx) {
+#ifdef DC_ABL_M_NODMA  // ablation: no LDS-DMA in the main loop (stale tiles, wrong results): its issue cost
+    if (hc > 0 || s >= 2) return;
+#endif
     const uint32_t base = lds0 + slot * M_SLOT;
     const int q = wave + 8 * idx;
     if (s < M_T1) {
@@ -1030,7 +1033,9 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
     if (n_new == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n_new == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DC_ABL_M_NOBAR  // ablation: no barrier per step (wrong results)
     __syncthreads();
+#endif
     cur = cur + 1 == M_S ? 0 : cur + 1;
   };
 
