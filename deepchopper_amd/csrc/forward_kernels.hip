@@ -1106,12 +1106,23 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
         afr2[1][0] = lds_read_b128<(0 * M_HC + 3 * 32) * 16>(aA);
         afr2[1][1] = lds_read_b128<(4 * M_HC + 3 * 32) * 16>(aA);
         group(std::integral_constant<int, 1>{}, afr[1]);
-        lds_wait<2>(afr2[0][0], afr2[0][1]);
+        if constexpr (ss == 1) {
+          lds_wait<0>(afr2[0][0], afr2[0][1], afr2[1][0], afr2[1][1]);
+          step_end(n_new);
+        } else {
+          lds_wait<2>(afr2[0][0], afr2[0][1]);
+        }
         group(std::integral_constant<int, 2>{}, afr2[0]);
         lds_wait<0>(afr2[1][0], afr2[1][1]);
+        // The step's barrier sits in front of its last two MFMA groups: every LDS read of this tile is complete here, the
+        // group only needs registers, and the next step's fragment reads issue right behind it -- the matrix pipe
+        // drains this tile while the next one's first fragments are in flight.  With the barrier after the group,
+        // all eight waves (both waves of every SIMD) opened each step with the pipe idle for a whole LDS round trip
+        // plus the LayerNorm-apply / split of the B fragment.  Measured -1 %: most of what the barrier costs (ablation
+        // without barriers: -17 %) is the lockstep itself -- both waves of a SIMD fetch, split and issue MFMAs in the
+        // same phases -- which no placement of one barrier per step removes.
         group(std::integral_constant<int, 3>{}, afr2[1]);
       });
-      step_end(n_new);
     }
     // ---------------- type 2: fc2 over this chunk's 128 hidden units, k-tiles of 32 (= one fc1 tile row) ----------------
     static_for<M_T2>([&](auto kc) {
@@ -1161,7 +1172,12 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
           constexpr int b = decltype(bc)::value;
           if constexpr (b + 1 < 8) {
             load_w(std::integral_constant<int, b + 1>{}, wf[(b + 1) & 1]);
-            lds_wait<2>(wf[b & 1][0], wf[b & 1][1]);
+            if constexpr (q == 1 && b == 6) {  // barrier in front of the step's last two groups (see the fc1 steps)
+              lds_wait<0>(wf[0][0], wf[0][1], wf[1][0], wf[1][1]);
+              step_end(n_new);
+            } else {
+              lds_wait<2>(wf[b & 1][0], wf[b & 1][1]);
+            }
           } else {
             lds_wait<0>(wf[b & 1][0], wf[b & 1][1]);
           }
@@ -1179,7 +1195,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
       });
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[mi][e] = 0.f;  // tile consumed: ready for the next chunk
-      step_end(n_new);
     });
   }
   if (__any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
