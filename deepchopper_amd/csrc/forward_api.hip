@@ -70,6 +70,7 @@ struct dc_model {
   int32_t* d_fft_reads = nullptr;
   int fft_count[5] = {0, 0, 0, 0, 0}, fft_offset[5] = {0, 0, 0, 0, 0};
   int max_P_mfma = 0;
+  int n_groups_long = 0;            // leading groups with reads above 1 024 tokens (16-block chunks); the rest fit one 32-block chunk
   std::vector<void*> owned;  // every weight allocation
   int64_t weight_bytes = 0;
 
@@ -534,6 +535,9 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   m->d_grp_P = (int32_t*)(dp + o_gp);
   m->d_fft_reads = (int32_t*)(dp + o_fr);
   m->max_P_mfma = maxP_mfma;
+  // reads are ordered longest first: the groups of more than 32 blocks (1 024 tokens) are a prefix
+  m->n_groups_long = 0;
+  for (int g = 0; g < n_groups; ++g) m->n_groups_long += grp_P[g] > 32;
   m->Tp = Tp;
   m->n_groups = n_groups;
   m->max_P = maxP;
@@ -684,9 +688,21 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
       const int hy = hy_env ? hy_env : (m->gemm_mode >= 1 ? 3 : 2);
       if (m->n_groups > 0) {
-        rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P_mfma)
-                     : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P_mfma)
-                               : launch_hyena3(st, a, m->n_groups, m->max_P_mfma);
+        static const bool one_launch = getenv("DC_H3_ONE_LAUNCH") != nullptr;  // A/B
+        if (hy == 3 && !one_launch && m->n_groups_long > 0 && m->n_groups_long < m->n_groups) {
+          // mixed lengths: the 32-block form (one filter window, measured 6 % faster at 1 kb) for the groups that fit
+          // it, the 16-block form only for the longer ones -- two launches over disjoint group ranges
+          rc = launch_hyena3(st, a, m->n_groups_long, m->max_P_mfma);
+          if (rc) return rc;
+          HyenaArgs b = a;
+          b.grp_reads = a.grp_reads + (size_t)m->n_groups_long * 32;
+          b.grp_P = a.grp_P + m->n_groups_long;
+          rc = launch_hyena3(st, b, m->n_groups - m->n_groups_long, 32);
+        } else {
+          rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P_mfma)
+                       : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P_mfma)
+                                 : launch_hyena3(st, a, m->n_groups, m->max_P_mfma);
+        }
         if (rc) return rc;
       }
       // long reads: O(L log L) FFT convolution, one launch per transform size present in the batch
