@@ -81,7 +81,6 @@ struct HyenaArgs {
   const int32_t* ntok;       // [n_reads] tokens (FFT long convolution: exact read length)
   int64_t Tp;
   int D;
-  int CH;              // channels per workgroup (1, 2 or 4)
   const unsigned short* kfp;  // hyena3: bf16 filter planes [D][3][8][kfp_nu][8] (reversed, 8 shifted copies)
   int kfp_nu;          // 16-byte units per (plane, shift) copy
   int kf_taps;         // taps of the materialised filter (multiple of 1024)
@@ -105,7 +104,6 @@ int mlp_fused_perm16(int kappa);
 int mlp_fused_perm(int k);       // k order of the fused MLP kernel's register-fed GEMMs: real row that logical k stands for
 int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (partials of EPI_HEAD2_FUSED)
 int launch_filter(hipStream_t st, const FilterArgs& f);
-int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 // O(L log L) long convolution for long reads (hyena_fft.hip): 2^logm complex points per (read, channel), logm 11..14

@@ -568,7 +568,7 @@ int run_head(dc_model* m, hipStream_t st, bool head_sums, bool head1_ready, floa
       (rc = run_gemm(m, st, "gemm_head1", WRef{m->Wt_l1, m->Wp_l1, m->Wq_l1, m->is_l1}, x, hm, m->b_l1, nullptr, qpad, true, EPI_BIAS_RELU_Q, D, H,
                      head_sums)))
     return rc;
-  static const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
+  const bool no_head_fuse = getenv("DC_NO_HEAD_FUSE") != nullptr;  // A/B switch
   if (m->gemm_mode >= 1 && !no_head_fuse) {
     // linear2 + residual + ReLU + linear3 in one kernel: the 1024-wide activation never reaches HBM
     if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_HEAD2_FUSED, H,
@@ -611,11 +611,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   const int64_t Tp = m->Tp;
 
   ProfScope whole(m, st, "forward");
-  static const bool no_fused_stats = getenv("DC_NO_FUSED_STATS") != nullptr;  // A/B switch
+  const bool no_fused_stats = getenv("DC_NO_FUSED_STATS") != nullptr;  // A/B switch
   // bf16x6 mode with the layer-0 table: every LayerNorm input is produced by an out_proj / fc2 GEMM whose
   // epilogue also accumulates the per-token sum and sum of squares -> no separate statistics pass
   const bool fused_stats = !no_fused_stats && m->gemm_mode >= 1;
-  static const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
+  const bool no_l0_table = getenv("DC_NO_L0_TABLE") != nullptr;  // A/B switch
   const bool l0_table = !no_l0_table && m->u_table0 != nullptr;
   // layer 0 with the 16-bit long convolution: its kernel gathers u from the per-token-id table itself, so the
   // embed kernel writes the packed token ids (1 B/token) instead of u (3 KB/token)
@@ -631,11 +631,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
                                  m->d_src_base, m->d_ntok, Tp, x, qpad);
     if (rc) return rc;
   }
-  // channels per workgroup of the long-convolution kernel: keep all four waves busy on short reads
-  const int nchunk_min = (std::max(m->max_P_mfma, 1) + 3) / 4;
-  const int CH = nchunk_min >= 7 ? 1 : (nchunk_min >= 3 ? 2 : 4);
-
-  static const bool no_mlp_chain = getenv("DC_NO_MLP_CHAIN") != nullptr;  // A/B switch
+  const bool no_mlp_chain = getenv("DC_NO_MLP_CHAIN") != nullptr;  // A/B switch
   bool u_ready = false;     // the previous block's fused MLP kernel already produced this block's in_proj output
   bool head1_ready = false;  // ... or the head's linear1 output (last block)
   for (int li = 0; li < c.n_layer; ++li) {
@@ -670,7 +666,6 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.ntok = m->d_ntok;
       a.Tp = Tp;
       a.D = D;
-      a.CH = CH;
       a.kfp = L.kfp;
       a.kfp_nu = hyena3_units((int)m->kf_taps);
       a.kf_taps = (int)m->kf_taps;
@@ -684,11 +679,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         a.vocab = c.vocab;
       }
       ProfScope ps(m, st, "hyena");
-      // long-convolution kernel: 3 = bf16x6 MFMA (with the bf16x6 GEMM mode), 2 = fp32 MFMA, 1 = first version
-      static const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
+      // long-convolution kernel: 3 = 16-bit split MFMA (with the split GEMM modes), 2 = fp32 MFMA
+      const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
       const int hy = hy_env ? hy_env : (m->gemm_mode >= 1 ? 3 : 2);
       if (m->n_groups > 0) {
-        static const bool one_launch = getenv("DC_H3_ONE_LAUNCH") != nullptr;  // A/B
+        const bool one_launch = getenv("DC_H3_ONE_LAUNCH") != nullptr;  // A/B
         if (hy == 3 && !one_launch && m->n_groups_long > 0 && m->n_groups_long < m->n_groups) {
           // mixed lengths: the 32-block form (one filter window, measured 6 % faster at 1 kb) for the groups that fit
           // it, the 16-block form only for the longer ones -- two launches over disjoint group ranges
@@ -699,9 +694,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
           b.grp_P = a.grp_P + m->n_groups_long;
           rc = launch_hyena3(st, b, m->n_groups - m->n_groups_long, 32);
         } else {
-          rc = hy == 1 ? launch_hyena(st, a, m->n_groups, m->max_P_mfma)
-                       : hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P_mfma)
-                                 : launch_hyena3(st, a, m->n_groups, m->max_P_mfma);
+          rc = hy == 2 ? launch_hyena2(st, a, m->n_groups, m->max_P_mfma) : launch_hyena3(st, a, m->n_groups, m->max_P_mfma);
         }
         if (rc) return rc;
       }
@@ -721,7 +714,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       ProfScope ps(m, st, "ln_stats");
       if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
-    static const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
+    const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
     if (m->gemm_mode == 2 && sums && !no_mlp_fuse && m->mlp_fusion && L.Wq_fc2p && D == 256 && DI % 128 == 0 && DI <= 1024) {
       // fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide activation stays
       // in registers (fp16x3 only)

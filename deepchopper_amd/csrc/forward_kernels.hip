@@ -135,11 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
           s0[ni] = fmaf(v, wa, s0[ni]);
           s1[ni] = fmaf(v, wc, s1[ni]);
         } else {
-#ifdef DC_ABL_NOEPI
-          asm volatile("" ::"v"(v));
-#else
           cp[(int64_t)((e & 3) + 8 * (e >> 2)) * g.Tp] = v;
-#endif
         }
       }
     }
@@ -245,9 +241,7 @@ __global__ __launch_bounds__(256, DC_G_OCC) void gemm_kernel(GemmArgs g) {
   const int nk = g.K / G_BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-#ifndef DC_ABL_NOLOAD
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);  // lands in the other buffer while this one is consumed
-#endif
 
     const float* pA = &sA[cur][h][wn * 64 + i];
     const float* pB = &sB[cur][h][wt * 64 + i];
@@ -308,9 +302,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef DC_H_OCC
 #define DC_H_OCC 2   // launch bound (waves per SIMD) of gemm6_kernel: the allocator may use up to 256 VGPRs, it needs <= 128
 #endif
-#ifndef DC_HP_OCC
-#define DC_HP_OCC 4  // persistent gemm6p_kernel: capped at 128 VGPRs so that two 8-wave workgroups share a CU
-#endif
 constexpr int H_BK = DC_H_BK;      // k-tile depth
 constexpr int H_OPT = H_BK / 8;    // k-octets per tile
 
@@ -337,12 +328,6 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hh, bf16x8& 
 #endif
 #ifndef DC_H_COMPILER_LDS
 #define DC_H_COMPILER_LDS 0   // 1: leave the fragment reads of the fp16x3 GEMM to the compiler (A/B)
-#endif
-#ifndef DC_H_PERSIST_STATS
-#define DC_H_PERSIST_STATS 0   // 1: out_proj / fc2 (statistics epilogue) through the persistent kernel
-#endif
-#ifndef DC_H_PERSIST_DEFAULT
-#define DC_H_PERSIST_DEFAULT 0
 #endif
 #ifndef DC_H_BN
 #define DC_H_BN 128   // output channels per block
@@ -441,16 +426,6 @@ struct SplitMode<1> {
   static constexpr int NP = 2;
   static __device__ __forceinline__ bool split(const float (&x)[8], vec (&o)[2]) {
     bool ovf = false;
-#ifdef DC_ABL_NOSPLIT
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const f32x2 v = {x[j], x[j + 1]};
-      const f16x2 hp = __builtin_convertvector(v, f16x2);
-      o[0][j] = hp[0]; o[0][j + 1] = hp[1];
-    }
-    o[1] = o[0];
-    return false;
-#endif
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       ovf = ovf || !(fabsf(x[j]) <= 65504.f) || !(fabsf(x[j + 1]) <= 65504.f);  // also catches NaN
@@ -551,11 +526,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_core(const GemmArgs& g, PatchW
           }
         }
         if (EPI != EPI_HEAD2_FUSED) {
-#ifdef DC_ABL_NOEPI
-          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
-#else
           *reinterpret_cast<float4*>(g.C + (int64_t)n * g.Tp + t) = make_float4(o[0], o[1], o[2], o[3]);
-#endif
         }
         (void)n;
       }
@@ -700,16 +671,12 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
 #pragma unroll
       for (int it = 0; it < A_PER; ++it) {
         glds16(reinterpret_cast<const float*>(a_src[it]), a_dst[it] + buf * BUF);
-#ifndef DC_ABL_SAMEK_A
         a_src[it] += a_step;
-#endif
       }
 #pragma unroll
       for (int it = 0; it < B_PER; ++it) {
         glds16(b_src[it], b_dst[it] + buf * BUF);
-#ifndef DC_ABL_SAMEK_B
         b_src[it] += b_step;
-#endif
       }
       return;
     }
@@ -785,9 +752,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     const bool do_stage = kt + S - 1 < nk;
     int nxt = cur + S - 1;
     if (nxt >= S) nxt -= S;
-#ifndef DC_ABL_NOLOAD
     if (!ILV && do_stage) stage(nxt, kt + S - 1);  // overwrites the buffer consumed in iteration kt-1 (all waves passed its barrier)
-#endif
     const unsigned char* bufp = smem6 + cur * BUF;
     const svec* pA = reinterpret_cast<const svec*>(bufp);
     const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
@@ -817,17 +782,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
           x[2 * j + 1] = LN ? fmaf(xb[j][1], rs[0], nm[0]) : xb[j][1];
         }
         svec bs[2];
-#ifdef DC_ABL_H_NOSPLIT  // ablation: B operand as if it arrived pre-split (cvt only, wrong results)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x2 v2 = {x[2 * j], x[2 * j + 1]};
-          const f16x2 hp = __builtin_convertvector(v2, f16x2);
-          bs[0][2 * j] = hp[0]; bs[0][2 * j + 1] = hp[1];
-        }
-        bs[1] = bs[0];
-#else
         SM::split_mx(x, bs, mx);
-#endif
         static_for<H_MI>([&](auto mc) {
           constexpr int mi = decltype(mc)::value;
           lds_wait<2 * (H_MI - 1 - mi)>(afr[mi][0], afr[mi][1]);
@@ -858,11 +813,7 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
           float x[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-#ifdef DC_ABL_NOSPLIT
-            x[j] = xr[ni][j];
-#else
             x[j] = LN ? fmaf(xr[ni][j], rs[ni], nm[ni]) : xr[ni][j];
-#endif
           }
           SM::split_mx(x, bs[ni], mx);
         }
@@ -876,30 +827,17 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
     }
       });
     // next iteration reads tile kt+1: it has landed when only the tiles younger than it are outstanding
-#ifndef DC_ABL_NOVMWAIT
     if (S == 2 || kt + S - 1 >= nk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // S > 2: ring draining, at most S-2 short iterations
     } else {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * PW) : "memory");
     }
-#endif
-#ifndef DC_ABL_NOBARRIER
     __syncthreads();
-#endif
     cur = cur + 1 == S ? 0 : cur + 1;
   }
   if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
   DC_STAMP_T(st2);
-#ifdef DC_H_DIRECT_EPI
-  gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
-#else
-#ifdef DC_ABL_SKIPEPI
-#pragma unroll
-  for (int a = 0; a < H_MI; ++a) asm volatile("" ::"v"(acc[a][0]));
-#else
   gemm_epilogue_lds<EPI, H_MI, H_NI>(g, acc, reinterpret_cast<float*>(smem6) + wave * 1024, n_blk, t_blk + t_w, lane);
-#endif
-#endif
 #ifdef DC_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left the wave
   DC_STAMP_T(st3);
@@ -980,9 +918,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   //      piece `idx` of a wave is piece number wave + 8 * idx of the tile ----
   const uint32_t voff = lane * 16;
   auto issue_one = [&](int hc, int s, int slot, int idx) {
-#ifdef DC_ABL_M_NODMA  // ablation: no LDS-DMA in the main loop (stale tiles, wrong results): its issue cost
-    if (hc > 0 || s >= 2) return;
-#endif
     const uint32_t base = lds0 + slot * M_SLOT;
     const int q = wave + 8 * idx;
     if (s < M_T1) {
@@ -992,12 +927,7 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
         glds16_s(a1, voff, base + ((pl * 4 + o) * M_HC + seg * 64) * 16);
       } else {
         const int row = q - 16;
-#ifdef DC_ABL_M_XHOT  // ablation: every X tile is k-tile 0 (32 KiB per workgroup, cache resident): how much of the
-                      // kernel is the 8x re-streaming of the 256 KiB X tile through the memory system?  (wrong results)
-        glds16_s(g.X + (int64_t)row * g.Tp + t_blk, voff, base + M_A1 + row * 1024);
-#else
         glds16_s(g.X + (int64_t)(32 * s + row) * g.Tp + t_blk, voff, base + M_A1 + row * 1024);
-#endif
       }
     } else {
       const int pl = q >> 4, o = (q >> 2) & 3, seg = q & 3;
@@ -1033,9 +963,7 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
     if (n_new == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n_new == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef DC_ABL_M_NOBAR  // ablation: no barrier per step (wrong results)
     __syncthreads();
-#endif
     cur = cur + 1 == M_S ? 0 : cur + 1;
   };
 
@@ -1067,23 +995,12 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
         lds_wait<4>(xb[0], xb[1], xb[2], xb[3]);
         float x[8];
         svec bs[2];
-#ifdef DC_ABL_M_NOSPLIT1  // ablation: what the type-1 steps would cost with LN(x) pre-split (cvt only, wrong results)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x[2 * j] = xb[j][0];
-          x[2 * j + 1] = xb[j][1];
-          const f16x2 hp = __builtin_convertvector(xb[j], f16x2);
-          bs[0][2 * j] = hp[0]; bs[0][2 * j + 1] = hp[1];
-        }
-        bs[1] = bs[0];
-#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           x[2 * j] = fmaf(xb[j][0], rs, nm);
           x[2 * j + 1] = fmaf(xb[j][1], rs, nm);
         }
         SM::split_mx(x, bs, mx);
-#endif
         auto group = [&](auto mc, u32x4 (&f)[2]) {
           constexpr int mi = decltype(mc)::value;
           const svec af[2] = {__builtin_bit_cast(svec, f[0]), __builtin_bit_cast(svec, f[1])};
@@ -1148,17 +1065,7 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
           hv[j] = TANH ? gelu_tanh(v) : gelu_erf(v);
         }
         svec hf[2];
-#ifdef DC_ABL_M_NOGELU2  // ablation: the type-2 steps without GELU and split (cvt only, wrong results)
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const f32x2 v2 = {acc1[mi][8 * q + j], acc1[mi][8 * q + j + 1]};
-          const f16x2 hp = __builtin_convertvector(v2, f16x2);
-          hf[0][j] = hp[0]; hf[0][j + 1] = hp[1];
-        }
-        hf[1] = hf[0];
-#else
         SM::split_mx(hv, hf, mx);
-#endif
         // A fragments of the 8 output tiles: one tile (2 reads) per batch, one batch ahead of its MFMAs
         const uint32_t aW = lds0 + cur * M_SLOT + ((2 * q + h) * M_D + i) * 16;
         u32x4 wf[2][2];  // [batch parity][plane]
@@ -1360,7 +1267,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   }
 }
 
-#include "mlp4_kernel.inc"
 // k order of the fused MLP kernel's register-fed GEMMs.  (A v_mfma_f32_16x16x32_f16 form of the kernel with a
 // 32-group permutation was measured 15 % slower -- commit 8d24a79, profiles/r02_mlp_shape16_and_valu_ablations.json.)
 int mlp_fused_perm(int k) { return (k & ~15) + mlp_perm16(k & 15); }
@@ -1372,28 +1278,6 @@ int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   if (g.Wp3)
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && g.N3 <= 1024 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
                "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
-  // default: the 8-wave form (256 tokens per workgroup, X tile streamed once per hidden chunk).  DC_MLP_WAVES=4
-  // selects the 4-wave form that keeps the token tile in registers and reads X once: it moves 10x less fabric
-  // traffic but 15 % more LDS-DMA bytes per token (weights per 128 instead of 256 tokens: 21.5 vs 18.7 KB) and,
-  // at one wave per SIMD, cannot hide their issue cost behind a partner wave -- measured 10.4-10.9 ms against
-  // 9.0-9.1 ms per launch (profiles/r02_mlp4_*).
-  static const bool four = getenv("DC_MLP_WAVES") && atoi(getenv("DC_MLP_WAVES")) == 4;
-  if (four) {
-    const dim3 grid4((unsigned)(g.Tp / Q_BT)), block4(64 * Q_NW);
-    if (g.Wp3 && g.epi3 == EPI_BIAS) {
-      if (g.gelu_tanh) hipLaunchKernelGGL((mlp4_kernel<true, EPI_BIAS>), grid4, block4, 0, st, g);
-      else hipLaunchKernelGGL((mlp4_kernel<false, EPI_BIAS>), grid4, block4, 0, st, g);
-    } else if (g.Wp3) {
-      if (g.gelu_tanh) hipLaunchKernelGGL((mlp4_kernel<true, EPI_BIAS_RELU_Q>), grid4, block4, 0, st, g);
-      else hipLaunchKernelGGL((mlp4_kernel<false, EPI_BIAS_RELU_Q>), grid4, block4, 0, st, g);
-    } else if (g.gelu_tanh) {
-      hipLaunchKernelGGL((mlp4_kernel<true, -1>), grid4, block4, 0, st, g);
-    } else {
-      hipLaunchKernelGGL((mlp4_kernel<false, -1>), grid4, block4, 0, st, g);
-    }
-    DC_LAUNCH_CHECK();
-    return DC_OK;
-  }
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
   if (g.Wp3) {
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
@@ -1414,217 +1298,13 @@ int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   return DC_OK;
 }
 
-// Persistent variant of gemm6 for the short-K (K = 256) GEMMs: a workgroup walks several output tiles
-// and requests the first k-tile of its next tile while the last k-tile of the current one is consumed,
-// so the LDS-DMA stream never drains at tile boundaries (no exposed prologue latency per tile).
-// Tiles are dealt per XCD (n fastest) so the blocks of one XCD work on the same token panels.
-template <int EPI, bool LN, int MODE>
-__global__ __launch_bounds__(64 * DC_H_NW, DC_HP_OCC) void gemm6p_kernel(GemmArgs g) {
-  typedef SplitMode<MODE> SM;
-  typedef typename SM::vec svec;
-  constexpr int H_A_BYTES = SM::NP * H_BK * H_BN * 2;
-  constexpr int BUF = H_A_BYTES + H_B_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * BUF];
-
-  const int n_blocks = g.N / H_BN;
-  const unsigned total = (unsigned)n_blocks * (unsigned)(g.Tp / H_BT);
-  // contiguous logical tile range of this block's XCD, then round-robin over the XCD's blocks
-  const unsigned xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const unsigned q8 = total >> 3, r8 = total & 7u;
-  const unsigned x_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const unsigned x_n = q8 + (xcd < r8 ? 1u : 0u);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t_w = wave * (32 * H_NI);
-  const int i = lane & 31, h = lane >> 5;
-  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem6));
-  constexpr int A_SEG = H_BN / 64;
-  constexpr int A_INSTR = SM::NP * H_OPT * A_SEG;
-  constexpr int B_INSTR = H_B_BYTES / 1024;
-  const int K8 = g.K >> 3;
-  const int b_row_l = (lane * 4) / H_BT, b_col_l = (lane * 4) % H_BT;
-  constexpr int B_ROWS_PER_INSTR = 256 / H_BT > 0 ? 256 / H_BT : 1;
-  // fixed LDS-DMA slots per wave, source pointers stepped along k (see gemm6_kernel); set_tile() re-bases
-  // them when the workgroup moves to its next output tile
-  constexpr bool FAST = (A_INSTR % H_NW == 0) && (B_INSTR % H_NW == 0) && (H_BT >= 256);
-  constexpr int A_PER = FAST ? A_INSTR / H_NW : 1, B_PER = FAST ? B_INSTR / H_NW : 1;
-  const unsigned short* a_src[A_PER];
-  const float* b_src[B_PER];
-  uint32_t a_dst[A_PER], b_dst[B_PER];
-  int kt_next = 0, n_cur = 0;
-  int64_t t_cur = 0;
-  const int64_t a_step = (int64_t)H_OPT * g.N * 8, b_step = (int64_t)H_BK * g.Tp;
-  if (FAST) {
-#pragma unroll
-    for (int it = 0; it < A_PER; ++it) {
-      const int q = wave + it * H_NW;
-      a_dst[it] = lds0 + (((q / (A_SEG * H_OPT)) * H_OPT + (q / A_SEG) % H_OPT) * H_BN + (q % A_SEG) * 64) * 16;
-    }
-#pragma unroll
-    for (int it = 0; it < B_PER; ++it) b_dst[it] = lds0 + H_A_BYTES + (wave + it * H_NW) * 1024;
-  }
-  auto set_tile = [&](int n_blk, int64_t t_blk) {
-    n_cur = n_blk;
-    t_cur = t_blk;
-    kt_next = 0;
-    if (FAST) {
-#pragma unroll
-      for (int it = 0; it < A_PER; ++it) {
-        const int q = wave + it * H_NW;
-        const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
-        a_src[it] = g.Wp + ((((int64_t)pl * K8 + o) * g.N + n_blk + seg * 64 + lane) << 3);
-      }
-#pragma unroll
-      for (int it = 0; it < B_PER; ++it) {
-        const int bq = wave + it * H_NW;
-        b_src[it] = g.X + (int64_t)((bq * 256) / H_BT) * g.Tp + t_blk + (bq * 256) % H_BT + lane * 4;
-      }
-    }
-  };
-  auto stage = [&](int buf) {  // next k-tile of the tile given to set_tile()
-    if (FAST) {
-#pragma unroll
-      for (int it = 0; it < A_PER; ++it) {
-        glds16(reinterpret_cast<const float*>(a_src[it]), a_dst[it] + buf * BUF);
-        a_src[it] += a_step;
-      }
-#pragma unroll
-      for (int it = 0; it < B_PER; ++it) {
-        glds16(b_src[it], b_dst[it] + buf * BUF);
-        b_src[it] += b_step;
-      }
-      return;
-    }
-    const int kt = kt_next++;
-    for (int q = wave; q < A_INSTR + B_INSTR; q += H_NW) {  // wave-uniform
-      if (q < A_INSTR) {
-        const int pl = q / (A_SEG * H_OPT), o = (q / A_SEG) % H_OPT, seg = q % A_SEG;
-        const unsigned short* src =
-            g.Wp + ((((int64_t)pl * K8 + (int64_t)kt * H_OPT + o) * g.N + n_cur + seg * 64 + lane) << 3);
-        glds16(reinterpret_cast<const float*>(src), lds0 + buf * BUF + ((pl * H_OPT + o) * H_BN + seg * 64) * 16);
-      } else {
-        const int bq = q - A_INSTR;
-        const int row = (H_BT >= 256) ? (bq * 256) / H_BT : bq * B_ROWS_PER_INSTR + b_row_l;
-        const int col = (H_BT >= 256) ? (bq * 256) % H_BT + lane * 4 : b_col_l;
-        const float* src = g.X + ((int64_t)kt * H_BK + row) * g.Tp + t_cur + col;
-        glds16(src, lds0 + buf * BUF + H_A_BYTES + bq * 1024);
-      }
-    }
-  };
-  const int nk = g.K / H_BK;
-  if (jb >= x_n) return;  // block-uniform: fewer tiles than blocks on this XCD
-  float mx = 0.f;         // fp16x3 range guard: running max |activation| (SplitMode<1>::split_mx)
-
-  unsigned loc = jb;
-  int n_blk = (int)((x_lo + loc) % n_blocks) * H_BN;
-  int64_t t_blk = (int64_t)((x_lo + loc) / n_blocks) * H_BT;
-  set_tile(n_blk, t_blk);
-  stage(0);
-  int cur = 0;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  while (true) {
-    const unsigned loc_next = loc + per_xcd;
-    const bool has_next = loc_next < x_n;
-    const int n_next = has_next ? (int)((x_lo + loc_next) % n_blocks) * H_BN : 0;
-    const int64_t t_next = has_next ? (int64_t)((x_lo + loc_next) / n_blocks) * H_BT : 0;
-
-    float rs[H_NI], nm[H_NI];
-#pragma unroll
-    for (int ni = 0; ni < H_NI; ++ni) {
-      rs[ni] = 1.f;
-      nm[ni] = 0.f;
-      if (LN) {
-        const int64_t t = t_blk + t_w + ni * 32 + i;
-        float m = g.mean[t], r = g.rstd[t];
-        if (g.stats_are_sums) {
-          m = m / (float)g.K;
-          const float var = fmaxf(r / (float)g.K - m * m, 0.f);
-          r = 1.0f / sqrtf(var + g.ln_eps);
-        }
-        rs[ni] = r;
-        nm[ni] = -m * r;
-      }
-    }
-    f32x16 acc[H_MI][H_NI];
-#pragma unroll
-    for (int a = 0; a < H_MI; ++a)
-#pragma unroll
-      for (int b = 0; b < H_NI; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) stage(cur ^ 1);
-      else if (has_next) {  // first k-tile of the next output tile
-        set_tile(n_next, t_next);
-        stage(cur ^ 1);
-      }
-      const unsigned char* bufp = smem6 + cur * BUF;
-      const svec* pA = reinterpret_cast<const svec*>(bufp);
-      const float* pB = reinterpret_cast<const float*>(bufp + H_A_BYTES);
-#pragma unroll
-      for (int s = 0; s < H_BK / 16; ++s) {
-        svec bs[H_NI][SM::NP];
-#pragma unroll
-        for (int ni = 0; ni < H_NI; ++ni) {
-          float x[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float v = pB[(16 * s + 8 * h + j) * H_BT + t_w + ni * 32 + i];
-            x[j] = LN ? fmaf(v, rs[ni], nm[ni]) : v;
-          }
-          SM::split_mx(x, bs[ni], mx);
-        }
-#pragma unroll
-        for (int mi = 0; mi < H_MI; ++mi) {
-          svec af[SM::NP];
-#pragma unroll
-          for (int pl = 0; pl < SM::NP; ++pl) af[pl] = pA[(pl * H_OPT + 2 * s + h) * H_BN + mi * 32 + i];
-#pragma unroll
-          for (int ni = 0; ni < H_NI; ++ni) {
-            acc[mi][ni] = SM::mma(af, bs[ni], acc[mi][ni]);
-          }
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
-    }
-    // no LDS-DMA in flight here; buffer `cur` already holds the next tile's first k-tile
-    gemm_epilogue<EPI, H_MI, H_NI>(g, acc, n_blk, t_blk + t_w, i, h);
-    if (!has_next) break;
-    loc = loc_next;
-    n_blk = n_next;
-    t_blk = t_next;
-  }
-  if (MODE == 1 && __any(!(mx <= 65504.f)) && lane == 0) atomicAdd(g.overflow, 1);
-}
-
 template <int EPI, bool LN>
 static int launch_gemm_t(hipStream_t st, const GemmArgs& g) {
   const unsigned grid = (unsigned)((g.N / G_BN) * (g.Tp / G_BT));
   if (g.Wp) {
     DC_REQUIRE(g.K % H_BK == 0 && g.Tp % H_BT == 0 && g.N % H_BN == 0, "shape not aligned to the bf16x6 tile");
     const unsigned grid6 = (unsigned)((g.N / H_BN) * (g.Tp / H_BT));
-    static const int persist = getenv("DC_GEMM_PERSIST") ? atoi(getenv("DC_GEMM_PERSIST")) : DC_H_PERSIST_DEFAULT;
-    // persist: 0 = one tile per workgroup, 1 = persistent for K <= 256, 2 = persistent for every GEMM,
-    // 3 = measured best per epilogue: persistent (direct epilogue) except for the GELU and fused-head epilogues
-    static const int persist_stats = getenv("DC_GEMM_PERSIST_STATS") ? atoi(getenv("DC_GEMM_PERSIST_STATS")) : DC_H_PERSIST_STATS;
-    if ((persist == 1 && g.K <= 256) || persist == 2 ||
-        (persist == 3 && EPI != EPI_BIAS_GELU && EPI != EPI_HEAD2_FUSED) ||
-        (EPI == EPI_BIAS_RES_STATS && persist_stats)) {
-      // one wave of workgroups: (DC_HP_OCC waves per SIMD x 4 SIMDs / waves per workgroup) x 256 CUs
-      unsigned gp = 256u * (unsigned)((DC_HP_OCC * 4 / H_NW) > 0 ? (DC_HP_OCC * 4 / H_NW) : 1);
-      if (gp > grid6) gp = (grid6 + 7u) & ~7u;
-      if (g.split_mode == 1)
-        hipLaunchKernelGGL((gemm6p_kernel<EPI, LN, 1>), dim3(gp), dim3(64 * H_NW), 0, st, g);
-      else
-        hipLaunchKernelGGL((gemm6p_kernel<EPI, LN, 0>), dim3(gp), dim3(64 * H_NW), 0, st, g);
-    } else if (g.split_mode == 1)
+    if (g.split_mode == 1)
       hipLaunchKernelGGL((gemm6_kernel<EPI, LN, 1>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
     else
       hipLaunchKernelGGL((gemm6_kernel<EPI, LN, 0>), dim3(grid6), dim3(64 * H_NW), 0, st, g);
@@ -1835,120 +1515,6 @@ __device__ __forceinline__ void load_window20(const float* __restrict__ row, int
     w[4 * j + 1] = v[j].y;
     w[4 * j + 2] = v[j].z;
     w[4 * j + 3] = v[j].w;
-  }
-}
-
-__global__ __launch_bounds__(256) void hyena_kernel(HyenaArgs a) {
-  extern __shared__ float s_k[];  // [CH][32 + 32 * P]
-  const int g = blockIdx.x;
-  const int P = a.grp_P[g];
-  const int CH = a.CH;
-  const int c_base = blockIdx.y * CH;
-  const int kstride = 32 + 32 * P;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, h = lane >> 5;
-
-  for (int ch = 0; ch < CH; ++ch) {
-    const float* krow = a.kf + (int64_t)(c_base + ch) * a.kf_stride;
-    float* dst = s_k + ch * kstride;
-    for (int j = tid; j < kstride; j += 256) dst[j] = j < 32 ? 0.f : krow[j - 32];
-  }
-  __syncthreads();
-
-  int r = a.grp_reads[g * 32 + n];
-  const bool valid = r >= 0;
-  if (!valid) r = a.grp_reads[g * 32];  // first slot of a group is always a real read
-  const int64_t off = a.toff[r];
-  const int my_nblk = valid ? a.nblk[r] : 0;
-
-  const int nchunk = (P + 3) >> 2;
-  const int npairs = (nchunk + 1) >> 1;
-  const int n_items = npairs * CH;
-
-  for (int item = wave; item < n_items; item += 4) {
-    const int ch = item % CH;
-    const int pair = item / CH;
-    const int c = c_base + ch;
-    const float* kp = s_k + ch * kstride;
-    const float* ux0 = a.u + (int64_t)c * a.Tp + off;
-    const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + off;
-    const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + off;
-    float* yrow = a.y + (int64_t)c * a.Tp + off;
-    const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
-    const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
-                bx1 = a.sb[a.D + c];
-    const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
-                wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
-
-    for (int half = 0; half < 2; ++half) {
-      const int chunk = half == 0 ? pair : nchunk - 1 - pair;
-      if (half == 1 && chunk == pair) break;  // middle chunk of an odd count
-      const int p0 = chunk * 4;
-      f32x16 acc[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[jj][e] = 0.f;
-
-      const int pmax = (p0 + 3 < P - 1) ? p0 + 3 : P - 1;
-      for (int p = 0; p <= pmax; ++p) {
-        // ---- B fragment: z[t] for t = 32p + 16h + s, s = 0..15 ----
-        const int64_t t0 = 32 * p + 16 * h;
-        const bool active = p < my_nblk;
-        float w1[20], wv[20];
-        load_window20(ux1, t0, t0 > 0, active, w1);
-        load_window20(uv, t0, t0 > 0, active, wv);
-        float zf[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          // conv1d(padding=2)[..., :L]: out[t] = w0 u[t-2] + w1 u[t-1] + w2 u[t] + b
-          const float c1 = fmaf(wx1_0, w1[s + 2], fmaf(wx1_1, w1[s + 3], fmaf(wx1_2, w1[s + 4], bx1)));
-          const float cv = fmaf(wv_0, wv[s + 2], fmaf(wv_1, wv[s + 3], fmaf(wv_2, wv[s + 4], bv)));
-          zf[s] = active ? c1 * cv : 0.f;
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int pp = p0 + jj;
-          if (pp >= p && pp < P) {  // wave-uniform
-            const int base = 32 + 32 * (pp - p) + n - 16 * h;
-            float af[16];  // all 16 taps of this Toeplitz block are requested before the first MFMA
-#pragma unroll
-            for (int s = 0; s < 16; ++s) af[s] = kp[base - s];
-#ifdef DC_HY_FENCE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-              acc[jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], zf[s], acc[jj], 0, 0, 0);
-          }
-        }
-      }
-
-      // ---- epilogue: y = conv * sf(x0); lane (n, h) holds q' = (e&3) + 8 (e>>2) + 4 h ----
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int pp = p0 + jj;
-        if (pp < P && valid && pp < my_nblk) {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const int64_t t = 32 * pp + 8 * gq + 4 * h;
-            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t > 0) lo = *reinterpret_cast<const float4*>(ux0 + t - 4);
-            const float4 cu = *reinterpret_cast<const float4*>(ux0 + t);
-            const float g0 = fmaf(wx0_0, lo.z, fmaf(wx0_1, lo.w, fmaf(wx0_2, cu.x, bx0)));
-            const float g1 = fmaf(wx0_0, lo.w, fmaf(wx0_1, cu.x, fmaf(wx0_2, cu.y, bx0)));
-            const float g2 = fmaf(wx0_0, cu.x, fmaf(wx0_1, cu.y, fmaf(wx0_2, cu.z, bx0)));
-            const float g3 = fmaf(wx0_0, cu.y, fmaf(wx0_1, cu.z, fmaf(wx0_2, cu.w, bx0)));
-            float4 o;
-            o.x = acc[jj][4 * gq + 0] * g0;
-            o.y = acc[jj][4 * gq + 1] * g1;
-            o.z = acc[jj][4 * gq + 2] * g2;
-            o.w = acc[jj][4 * gq + 3] * g3;
-            *reinterpret_cast<float4*>(yrow + t) = o;
-          }
-        }
-      }
-    }
   }
 }
 
@@ -2265,11 +1831,6 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   };
   auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
     l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef DC_H3_ABL_NOZLOAD  // ablation: the tile's inputs come from registers, not from memory (wrong results)
-    l1.x = c1.x = __builtin_bit_cast(float, (uint32_t)(0x01020300u + (p & 3)));
-    lv.y = cv.z = (float)p;
-    return;
-#endif
     if (TAB) {  // the token ids of positions t-4 .. t+3 travel in l1.x / c1.x; z_store looks the values up
       uint32_t il = 0xFFFFFFFFu, ic = 0xFFFFFFFFu;
       if (p < z_nblk) {
@@ -2349,14 +1910,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     // split of 4 values (padded to the 8-wide splitter) -> NP 8-byte stores
     const float z8[8] = {z[0], z[1], z[2], z[3], 0.f, 0.f, 0.f, 0.f};
     svec pl8[NP];
-#ifdef DC_H3_ABL_NOZSPLIT  // ablation: conversion only, no residual planes / range check (wrong results)
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pl8[q][j] = (decltype(pl8[q][j] + pl8[q][j]))z8[j];
-#else
     ovf = ovf || SM::split(z8, pl8);
-#endif
     unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (zr * H3_ZROW + zq4) * 2;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -2400,22 +1954,28 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     } else {  // filter window -> LDS: all of a thread's loads in flight before the first LDS write (the rolled
               // loop paid one L2 round trip per 16 bytes)
       constexpr int NW_IT = (NP * 8 * 132 + 255) / 256;  // n_units <= 132
-      svec wtmp[NW_IT];
+      // CB 16 runs three waves per SIMD (168 VGPRs): two batches of loads, so that the staging registers (4 per
+      // 16-byte load) do not push accumulators / addresses into scratch (the one-batch form spilled 5 dwords)
+      constexpr int NW_B = CB == 16 ? (NW_IT + 1) / 2 : NW_IT;
       const int n_w = NP * 8 * n_units;
 #pragma unroll
-      for (int k = 0; k < NW_IT; ++k) {
-        const int idx = tid + 256 * k;
-        if (idx < n_w) {
-          const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
-          wtmp[k] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
-        }
-      }
+      for (int k0 = 0; k0 < NW_IT; k0 += NW_B) {
+        svec wtmp[NW_B];
 #pragma unroll
-      for (int k = 0; k < NW_IT; ++k) {
-        const int idx = tid + 256 * k;
-        if (idx < n_w) {
-          const int cp = idx / n_units, j = idx - cp * n_units;
-          reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = wtmp[k];
+        for (int k = 0; k < NW_B; ++k) {
+          const int idx = tid + 256 * (k0 + k);
+          if (k0 + k < NW_IT && idx < n_w) {
+            const int cp = idx / n_units, j = idx - cp * n_units;  // cp = plane * 8 + shift
+            wtmp[k] = gfp[(int64_t)cp * a.kfp_nu + u_base + j];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NW_B; ++k) {
+          const int idx = tid + 256 * (k0 + k);
+          if (k0 + k < NW_IT && idx < n_w) {
+            const int cp = idx / n_units, j = idx - cp * n_units;
+            reinterpret_cast<svec*>(s_filt)[cp * H3_CS + j] = wtmp[k];
+          }
         }
       }
     }
@@ -2432,16 +1992,8 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 
     for (int p = p_in0; p <= p_in_last; ++p) {
       float4 l1, c1, lv, cv;
-#ifdef DC_H3_ABL_NOZ  // ablation: z tiles are not produced inside the loop (wrong results)
-      const bool more = false;
-#else
       const bool more = p < p_in_last;
-#endif
-#ifdef DC_H3_FULL_LOADS  // A/B: every thread also loads the four tokens in front of its own
-      if (more) z_load(p + 1, l1, c1, lv, cv);
-#else
       if (more) z_load_cur(p + 1, c1, cv);
-#endif
 
       // A (data) fragments: z[read r32][16 s + 8 h .. +7] of the three planes
       const unsigned char* zb = s_z + (p & 1) * H3_ZBUF_BYTES + (r32 * H3_ZROW + 8 * h) * 2;
@@ -2462,12 +2014,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
           for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
-#ifdef DC_H3_ABL_NOFK  // ablation: no filter-fragment LDS reads (wrong results)
-              fk[s][pl] = za[s][pl];
-              (void)fb;
-#else
               fk[s][pl] = fb[pl * 8 * H3_CS + 2 * s];
-#endif
             }
           f32x16 cacc = acc[m];
 #pragma unroll
@@ -2476,15 +2023,11 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
         }
       }
       if (more) {
-#ifndef DC_H3_FULL_LOADS
         neighbours(c1, cv, l1, lv);
-#endif
         z_store(p + 1, l1, c1, lv, cv);
         keep_tail(c1, cv);
       }
-#ifndef DC_H3_ABL_NOBAR  // ablation: no barrier per input tile (wrong results)
       __syncthreads();
-#endif
     }
   }
 
@@ -2585,7 +2128,7 @@ static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
+  const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
   if (max_P <= 32 && !cb16) {
     hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
   } else {
@@ -2604,19 +2147,6 @@ int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
     return tab ? launch_hyena3_t<1, true>(st, a, n_groups, max_P) : launch_hyena3_t<1, false>(st, a, n_groups, max_P);
   }
   return tab ? launch_hyena3_t<0, true>(st, a, n_groups, max_P) : launch_hyena3_t<0, false>(st, a, n_groups, max_P);
-}
-
-int launch_hyena(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
-  DC_REQUIRE(a.D % a.CH == 0, "CH must divide D");
-  const size_t lds = (size_t)a.CH * (32 + 32 * (size_t)max_P) * sizeof(float);
-  DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
-  if (lds > 64 * 1024) {
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL(hyena_kernel, dim3(n_groups, a.D / a.CH), dim3(256), lds, st, a);
-  DC_LAUNCH_CHECK();
-  return DC_OK;
 }
 
 // =====================================================================================

@@ -157,14 +157,3 @@ def test_synthetic_generators_are_deterministic():
     lab = synth.synth_label_stream(5000, seed=43)
     assert lab.dtype == np.int8 and 0 < lab.mean() < 0.5
     assert np.array_equal(lab, synth.synth_label_stream(5000, seed=43))
-
-
-def test_token_budget_batcher():
-    from deepchopper_amd.batcher import token_budget_batches
-
-    lens = [100, 5000, 31, 10000, 64, 900, 900]
-    r = list(token_budget_batches(lens, max_tokens=6000, max_reads=3))
-    assert r[0][0] == 0 and r[-1][1] == len(lens) and all(a[1] == b[0] for a, b in zip(r, r[1:]))
-    for a, b in r:
-        tok = sum((min(l, 32768) + 1 + 31) // 32 * 32 for l in lens[a:b])
-        assert b - a <= 3 and (tok <= 6000 or b - a == 1)

@@ -332,6 +332,44 @@ def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
     assert np.array_equal(outs[True][1], outs[False][1])
 
 
+AB_SWITCHES = [("DC_NO_HEAD_FUSE", "1"), ("DC_NO_FUSED_STATS", "1"), ("DC_NO_L0_TABLE", "1"), ("DC_NO_L0_GATHER", "1"),
+               ("DC_NO_MLP_CHAIN", "1"), ("DC_NO_MLP_FUSE", "1"), ("DC_HYENA", "2"), ("DC_H3_ONE_LAUNCH", "1"),
+               ("DC_H3_CB16", "1"), ("DC_NO_OUTPROJ_FUSE", "1")]
+
+
+@pytest.mark.parametrize("name,value", AB_SWITCHES, ids=[n for n, _ in AB_SWITCHES])
+def test_ab_switch_paths_match_oracle(hip_lib, monkeypatch, name, value):
+    """Every environment A/B switch that ships in the library selects a real, correct path (the unfused forms the
+    other GEMM modes use anyway): each one is held to the same tolerance as the default path, on a ragged batch with
+    reads on both sides of the 1 024-token chunk boundary of the long-convolution kernel."""
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = synthetic_state_dict(31)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    assert model.gemm_mode == "fp16x3"
+    rng = np.random.default_rng(31)
+    lens = np.array([40, 1500, 333, 1001, 2049, 64] + [200] * 30, np.int32)
+    B, stride = len(lens), int(lens.max())
+    ids = np.full((B, stride), 4, np.uint8)
+    q = np.zeros((B, stride), np.float32)
+    first = (stride - lens).astype(np.int32)
+    for b, n in enumerate(lens):
+        i1, q1 = _inputs(rng, 1, int(n))
+        ids[b, stride - n:], q[b, stride - n:] = i1[0], q1[0]
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    base = model.forward_ragged(d_ids, d_q, first, lens).cpu().numpy()
+    monkeypatch.setenv(name, value)
+    out = model.forward_ragged(d_ids, d_q, first, lens).cpu().numpy()
+    monkeypatch.delenv(name)
+    assert np.abs(out - base)[ids != 4].max() < 1e-4
+    for b in (0, 1, 3, 4):
+        n = int(lens[b])
+        ref = fr.forward(sd, ids[b: b + 1, stride - n:].astype(np.int64), q[b: b + 1, stride - n:]).numpy()[0]
+        _check(out[b, stride - n:], ref)
+
+
 def _robustness_cases():
     from deepchopper_amd.weights import BB, HD
 
@@ -450,5 +488,5 @@ def test_fft_long_convolution_matches_toeplitz_and_oracle(env, L):
         assert np.abs(out[1] - fft[0]).max() < 2e-5
         _check(out[0, L - Ls:], fr.forward(sd, i_s, q_s).numpy()[0])
     finally:
-        model.set_fft_threshold(3072)
+        model.set_fft_threshold(2560)  # the shipped default (forward_api.hip: fft_min_tokens)
         model.set_profiling(False)
