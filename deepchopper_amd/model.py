@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib, ops
-from .weights import HyenaDNAConfig, load_state_dict, synthetic_state_dict
+from .weights import HyenaDNAConfig, load_checkpoint, synthetic_state_dict
 
 # names `deepchopper predict --model` resolves on the HF Hub (cli.py:117-121)
 HUB_NAMES = {"rna002": "yangliz5/deepchopper", "rna004": "yangliz5/deepchopper-rna004"}
@@ -25,6 +25,10 @@ class TokenClassificationModel:
         self.net = ops.HipModel(state_dict, self.cfg)
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor) -> torch.Tensor:
+        """`TokenClassificationLit.forward` (basic_module.py:90-100).  SYNCHRONISES the stream in the default fp16x3
+        mode: the range guard's device counter is read back before the logits are handed out (a batch that left
+        the fp16 range is redone with the bf16 split).  Callers that pipeline forwards use
+        `self.net.forward(...)` with `set_overflow_target` (what `PredictPipeline.predict_stream` does)."""
         dev = torch.device("cuda", torch.cuda.current_device())
         ids = input_ids.to(dev)
         if ids.dtype not in (torch.int64, torch.uint8):
@@ -52,27 +56,30 @@ class DeepChopper:
     @staticmethod
     def from_checkpoint(checkpoint_path: str) -> TokenClassificationModel:
         """dc_hg.py:70-117: a Lightning `.ckpt` (its `state_dict`)."""
-        return TokenClassificationModel(load_state_dict(checkpoint_path))
+        return TokenClassificationModel(*load_checkpoint(checkpoint_path))
 
     @staticmethod
     def from_pretrained(model_name: str) -> TokenClassificationModel:
         """dc_hg.py:119-163.  `model_name` is a local directory / file holding the checkpoint the
         reference would download (`model.safetensors` written by PyTorchModelHubMixin).  Hub ids
         (`yangliz5/deepchopper`) are resolved through $DEEPCHOPPER_MODEL_DIR/<id> or the HF cache
-        if present; there is no network access in this build."""
+        if present; there is no network access in this build.  The file is read as the mixin wrote it: aliases of
+        shared tensors that `safetensors.torch.save_model` dropped are restored, buffers are recomputed if absent,
+        extra tensors are ignored, and the architecture is inferred from the tensor shapes and cross-checked
+        against a `config.json` next to the weights (`weights.load_checkpoint`)."""
         for cand in (model_name, os.path.join(os.environ.get("DEEPCHOPPER_MODEL_DIR", ""), model_name)):
             if cand and os.path.exists(cand):
-                return TokenClassificationModel(load_state_dict(cand))
+                return TokenClassificationModel(*load_checkpoint(cand))
         try:
             from huggingface_hub import snapshot_download
 
             path = snapshot_download(model_name, local_files_only=True)
-            return TokenClassificationModel(load_state_dict(path))
         except Exception as e:
             raise FileNotFoundError(
                 f"checkpoint '{model_name}' not found locally (set DEEPCHOPPER_MODEL_DIR or pass a path to "
                 f"model.safetensors / .ckpt); the HF Hub is not reachable from this environment: {e}"
             ) from None
+        return TokenClassificationModel(*load_checkpoint(path))
 
     @staticmethod
     def synthetic(seed: int = 0) -> TokenClassificationModel:

@@ -173,32 +173,245 @@ def _strip(sd: dict) -> dict[str, np.ndarray]:
     for k, v in sd.items():
         if hasattr(v, "detach"):
             v = v.detach().cpu().float().numpy()
+        if not isinstance(v, np.ndarray) and not np.isscalar(v):
+            continue  # non-tensor entries of a Lightning checkpoint's state (e.g. metric bookkeeping)
         out[k] = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
     return out
 
 
-def load_state_dict(path: str) -> dict[str, np.ndarray]:
-    """Load a DeepChopper checkpoint from a local path: a directory holding `model.safetensors`
-    (the layout `PyTorchModelHubMixin.save_pretrained` writes, dc_hg.py:140), a `.safetensors`
-    file, or a Lightning `.ckpt` / torch `.pt` with a `state_dict` (dc_hg.py:114-116)."""
-    if os.path.isdir(path):
-        for name in ("model.safetensors", "pytorch_model.bin"):
-            cand = os.path.join(path, name)
-            if os.path.exists(cand):
-                path = cand
-                break
-        else:
-            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+def _read_file(path: str) -> tuple[dict[str, np.ndarray], dict[str, str]]:
+    """(tensors, safetensors metadata).  `safetensors.torch.save_model` -- what PyTorchModelHubMixin.save_pretrained
+    calls -- drops every alias of a shared tensor and records `dropped name -> kept name` in the file's metadata."""
     if path.endswith(".safetensors"):
-        from safetensors.numpy import load_file
+        from safetensors import safe_open
 
-        return _strip(load_file(path))
+        tensors, meta = {}, {}
+        with safe_open(path, framework="pt") as fh:  # "pt": bf16 / fp16 checkpoints load too (numpy has no bf16)
+            meta = dict(fh.metadata() or {})
+            for k in fh.keys():
+                tensors[k] = fh.get_tensor(k)
+        return _strip(tensors), meta
     import torch
 
     obj = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(obj, dict) and "state_dict" in obj:
         obj = obj["state_dict"]
-    return _strip(obj)
+    return _strip(obj), {}
+
+
+def _find_weights(path: str) -> str:
+    if os.path.isdir(path):
+        for name in ("model.safetensors", "pytorch_model.bin"):
+            cand = os.path.join(path, name)
+            if os.path.exists(cand):
+                return cand
+        raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+    return path
+
+
+def _norm_name(k: str) -> str:
+    k = k.replace("._orig_mod.", ".").replace("_orig_mod.", "")
+    if k.startswith(("backbone.", "head.")):
+        k = "net." + k
+    return k
+
+
+def normalise_names(sd: dict) -> dict:
+    """Bring a state dict to the `net.backbone.backbone.* / net.head.*` names of `TokenClassificationLit`
+    (basic_module.py:58): accepts the bare `TokenClassificationModule` tree (no `net.`) and torch.compile's
+    `_orig_mod.` infix (basic_module.py `compile=True`)."""
+    return {_norm_name(k): v for k, v in sd.items()}
+
+
+def resolve_shared_tensors(sd: dict[str, np.ndarray], metadata: dict[str, str] | None = None) -> dict[str, np.ndarray]:
+    """Restore the aliases `safetensors.torch.save_model` removed.  HyenaDNA's filter MLP applies ONE `Sin` module
+    after each of its linears, so `implicit_filter.{1,3,5}.freq` are one tensor under three names and only the
+    first survives in `model.safetensors`; its metadata maps each dropped name to the kept one."""
+    out = dict(sd)
+    for dropped, kept in (metadata or {}).items():
+        if dropped not in out and kept in out:
+            out[dropped] = out[kept]
+    # without (or beyond) the metadata: any `...implicit_filter.<odd>.freq` stands for all of that filter's Sin slots
+    groups: dict[str, list[str]] = {}
+    for k in out:
+        if ".implicit_filter." in k and k.endswith(".freq"):
+            groups.setdefault(k.split(".implicit_filter.")[0], []).append(k)
+    for prefix, have in groups.items():
+        idx = sorted(int(k.split(".implicit_filter.")[1].split(".")[0]) for k in have)
+        # Sin slots sit at odd indices up to the last linear (an even index): fill every odd slot below it
+        last_linear = max([int(k.split(".implicit_filter.")[1].split(".")[0]) for k in out
+                           if k.startswith(prefix + ".implicit_filter.") and k.endswith(".weight")] or [idx[-1] + 1])
+        src = out[f"{prefix}.implicit_filter.{idx[0]}.freq"]
+        for j in range(1, last_linear, 2):
+            out.setdefault(f"{prefix}.implicit_filter.{j}.freq", src)
+    return out
+
+
+def infer_config(sd: dict[str, np.ndarray]) -> HyenaDNAConfig:
+    """Architecture constants read off the tensor shapes (the reference hard-wires them in dc_hg.py:142-152 and the
+    Hub config of LongSafari/hyenadna-small-32k-seqlen-hf; a checkpoint is the only thing that can confirm them)."""
+    def need(k):
+        if k not in sd:
+            raise KeyError(f"checkpoint has no tensor '{k}' (names must follow net.backbone.backbone.* / net.head.*; "
+                           f"found e.g. {sorted(sd)[:3]})")
+        return sd[k]
+
+    emb = need(BB + "embeddings.word_embeddings.weight")
+    n_layer = 0
+    while BB + f"layers.{n_layer}.mixer.in_proj.weight" in sd:
+        n_layer += 1
+    if n_layer == 0:
+        raise KeyError(f"checkpoint has no tensor '{BB}layers.0.mixer.in_proj.weight'")
+    f = BB + "layers.0.mixer.filter_fn."
+    w0 = need(f + "implicit_filter.0.weight")
+    n_lin = 0
+    while f + f"implicit_filter.{2 * n_lin}.weight" in sd:
+        n_lin += 1
+    cfg = HyenaDNAConfig()
+    cfg.d_model = int(emb.shape[1])
+    # vocab_size itself is not recoverable from the padded embedding; keep the multiple and report the padded size
+    cfg.vocab_size = int(emb.shape[0])
+    cfg.pad_vocab_size_multiple = 1
+    cfg.n_layer = n_layer
+    cfg.d_inner = int(need(BB + "layers.0.mlp.fc1.weight").shape[0])
+    cfg.filter_order = int(w0.shape[0])
+    cfg.emb_dim = int(w0.shape[1])
+    cfg.num_inner_mlps = n_lin - 2
+    cfg.short_filter_order = int(need(BB + "layers.0.mixer.short_filter.weight").shape[-1])
+    cfg.hyena_order = int(need(BB + "layers.0.mixer.in_proj.weight").shape[0]) // cfg.d_model - 1
+    if f + "pos_emb.z" in sd:
+        cfg.max_seq_len = int(np.asarray(sd[f + "pos_emb.z"]).reshape(-1, cfg.emb_dim).shape[0])
+    elif f + "pos_emb.t" in sd:
+        cfg.max_seq_len = int(np.asarray(sd[f + "pos_emb.t"]).size)
+    cfg.head_hidden = int(need(HD + "linear1.weight").shape[0])
+    cfg.num_class = int(need(HD + "linear3.weight").shape[0])
+    return cfg
+
+
+# HyenaDNAConfig field -> name in the Hub `config.json` of the backbone (configuration_hyena.py); same names
+_JSON_FIELDS = ("d_model", "d_inner", "n_layer", "hyena_order", "short_filter_order", "filter_order", "emb_dim",
+                "num_inner_mlps", "max_seq_len", "activation_freq", "layer_norm_epsilon")
+
+
+def check_config_json(cfg: HyenaDNAConfig, js: dict, where: str = "config.json") -> HyenaDNAConfig:
+    """Every architecture field `js` states must agree with what the tensors say; fields only the JSON knows
+    (activation_freq, layer_norm_epsilon, vocab_size / pad multiple) are taken from it.  A PyTorchModelHubMixin
+    `config.json` (the Lightning module's init kwargs) simply has none of these keys."""
+    shape_fields = ("d_model", "d_inner", "n_layer", "hyena_order", "short_filter_order", "filter_order", "emb_dim",
+                    "num_inner_mlps", "max_seq_len")
+    for name in _JSON_FIELDS:
+        if name not in js:
+            continue
+        want = js[name]
+        if name in shape_fields:
+            if int(want) != int(getattr(cfg, name)):
+                raise ValueError(f"{where}: field '{name}' = {want}, but the checkpoint's tensors have {name} = {getattr(cfg, name)}")
+        else:
+            setattr(cfg, name, float(want))
+    if "vocab_size" in js:
+        v, mult = int(js["vocab_size"]), int(js.get("pad_vocab_size_multiple", 1))
+        padded = v if v % mult == 0 else v + mult - v % mult
+        if padded != cfg.padded_vocab:
+            raise ValueError(f"{where}: field 'vocab_size' = {v} (padded to {padded} by pad_vocab_size_multiple = {mult}), "
+                             f"but the embedding table has {cfg.padded_vocab} rows")
+        cfg.vocab_size, cfg.pad_vocab_size_multiple = v, mult
+    return cfg
+
+
+def expected_shapes(cfg: HyenaDNAConfig) -> dict[str, tuple[tuple[int, ...], str]]:
+    """name -> (shape, the config expression it comes from)."""
+    D, DI, fo, e, H = cfg.d_model, cfg.d_inner, cfg.filter_order, cfg.emb_dim, cfg.head_hidden
+    W = (cfg.hyena_order + 1) * D
+    out = {BB + "embeddings.word_embeddings.weight": ((cfg.padded_vocab, D), "(padded vocab_size, d_model)"),
+           BB + "ln_f.weight": ((D,), "(d_model,)"), BB + "ln_f.bias": ((D,), "(d_model,)")}
+    for i in range(cfg.n_layer):
+        p = BB + f"layers.{i}."
+        for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "mlp.fc2.bias", "mixer.out_proj.bias",
+                  "mixer.filter_fn.bias"):
+            out[p + n] = ((D,), "(d_model,)")
+        out[p + "mlp.fc1.weight"] = ((DI, D), "(d_inner, d_model)")
+        out[p + "mlp.fc1.bias"] = ((DI,), "(d_inner,)")
+        out[p + "mlp.fc2.weight"] = ((D, DI), "(d_model, d_inner)")
+        m = p + "mixer."
+        out[m + "in_proj.weight"] = ((W, D), "((hyena_order + 1) * d_model, d_model)")
+        out[m + "in_proj.bias"] = ((W,), "((hyena_order + 1) * d_model,)")
+        out[m + "out_proj.weight"] = ((D, D), "(d_model, d_model)")
+        out[m + "short_filter.weight"] = ((W, 1, cfg.short_filter_order), "((hyena_order + 1) * d_model, 1, short_filter_order)")
+        out[m + "short_filter.bias"] = ((W,), "((hyena_order + 1) * d_model,)")
+        f = m + "filter_fn."
+        out[f + "pos_emb.z"] = ((1, cfg.max_seq_len, e), "(1, max_seq_len, emb_dim)")
+        out[f + "pos_emb.t"] = ((1, cfg.max_seq_len, 1), "(1, max_seq_len, 1)")
+        out[f + "modulation.deltas"] = ((1, 1, D), "(1, 1, d_model)")
+        dims = [e] + [fo] * (cfg.num_inner_mlps + 1)
+        for j in range(cfg.num_inner_mlps + 1):
+            out[f + f"implicit_filter.{2 * j}.weight"] = ((fo, dims[j]), "(filter_order, emb_dim | filter_order)")
+            out[f + f"implicit_filter.{2 * j}.bias"] = ((fo,), "(filter_order,)")
+            out[f + f"implicit_filter.{2 * j + 1}.freq"] = ((1, fo), "(1, filter_order)")
+        out[f + f"implicit_filter.{2 * (cfg.num_inner_mlps + 1)}.weight"] = ((D, fo), "(d_model, filter_order)")
+    out[HD + "linear1.weight"] = ((H, D), "(head lin1_size, d_model)")
+    out[HD + "linear1.bias"] = ((H,), "(head lin1_size,)")
+    out[HD + "linear2.weight"] = ((H, H), "(head lin2_size, lin1_size)")
+    out[HD + "linear2.bias"] = ((H,), "(head lin2_size,)")
+    out[HD + "linear3.weight"] = ((cfg.num_class, H), "(num_class, head lin2_size)")
+    out[HD + "linear3.bias"] = ((cfg.num_class,), "(num_class,)")
+    return out
+
+
+def complete_and_validate(sd: dict[str, np.ndarray], cfg: HyenaDNAConfig) -> dict[str, np.ndarray]:
+    """Recompute the input-independent buffers a checkpoint may omit (`pos_emb.t`, `modulation.deltas`: registered
+    buffers; `pos_emb.z` only if absent -- it is a trained parameter), then check every tensor the model needs
+    against the configuration.  Extra tensors (loss / metric state of the Lightning module) are ignored."""
+    out = dict(sd)
+    z0 = t0 = None
+    for i in range(cfg.n_layer):
+        f = BB + f"layers.{i}.mixer.filter_fn."
+        if f + "pos_emb.t" not in out or f + "pos_emb.z" not in out:
+            if z0 is None:
+                z0, t0 = positional_embedding(cfg)
+            out.setdefault(f + "pos_emb.t", t0.reshape(1, cfg.max_seq_len, 1))
+            out.setdefault(f + "pos_emb.z", z0)
+        out.setdefault(f + "modulation.deltas", modulation_deltas(cfg))
+    for name, (shape, expr) in expected_shapes(cfg).items():
+        if name not in out:
+            raise KeyError(f"checkpoint is missing tensor '{name}' {shape} = {expr}")
+        got = tuple(np.asarray(out[name]).shape)
+        if int(np.prod(got)) != int(np.prod(shape)) or (len(got) == len(shape) and got != shape):
+            raise ValueError(f"{name}: shape {got} does not match the configuration, expected {shape} = {expr}")
+    return out
+
+
+def load_checkpoint(path: str, cfg: HyenaDNAConfig | None = None) -> tuple[dict[str, np.ndarray], HyenaDNAConfig]:
+    """What `DeepChopper.from_pretrained` / `from_checkpoint` read (dc_hg.py:70-163): a directory holding
+    `model.safetensors` as `PyTorchModelHubMixin.save_pretrained` writes it (shared tensors de-duplicated), a
+    `.safetensors` file, or a Lightning `.ckpt` / torch `.pt` with a `state_dict` (dc_hg.py:114-116).  Returns the
+    completed state dict and the configuration inferred from it, cross-checked against a `config.json` /
+    `backbone_config.json` next to the weights when one states HyenaDNA fields."""
+    import json
+
+    wpath = _find_weights(path)
+    sd, meta = _read_file(wpath)
+    aliases = {_norm_name(k): _norm_name(v) for k, v in meta.items() if isinstance(v, str)}  # dropped name -> kept name
+    sd = resolve_shared_tensors(normalise_names(sd), aliases)
+    inferred = infer_config(sd)
+    if cfg is not None:  # an explicit configuration must agree with the tensors
+        check_config_json(inferred, {k: getattr(cfg, k) for k in _JSON_FIELDS if k not in ("activation_freq", "layer_norm_epsilon")},
+                          "explicit configuration")
+        for k in ("activation_freq", "layer_norm_epsilon", "gelu_approximate", "filter_shift"):
+            setattr(inferred, k, getattr(cfg, k))
+    folder = os.path.dirname(os.path.abspath(wpath))
+    for name in ("config.json", "backbone_config.json"):
+        cj = os.path.join(folder, name)
+        if os.path.exists(cj):
+            with open(cj) as fh:
+                js = json.load(fh)
+            if isinstance(js, dict):
+                check_config_json(inferred, js, cj)
+    return complete_and_validate(sd, inferred), inferred
+
+
+def load_state_dict(path: str) -> dict[str, np.ndarray]:
+    """The completed state dict of `load_checkpoint` (kept for callers that bring their own configuration)."""
+    return load_checkpoint(path)[0]
 
 
 def save_state_dict(sd: dict[str, np.ndarray], path: str) -> None:
