@@ -33,10 +33,6 @@ FLOPS_PER_TOKEN = {
     "mlp_fused": 2 * 256 * 1024 + 2 * 1024 * 256,
     "mlp_inproj_fused": 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 768,   # + the next block's in_proj
     "mlp_head1_fused": 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 1024,   # + the head's linear1
-    # round 3: the Hyena operator's out_proj runs as the fused kernel's prologue GEMM
-    "outproj_mlp_fused": 2 * 256 * 256 + 2 * 256 * 1024 + 2 * 1024 * 256,
-    "outproj_mlp_inproj_fused": 2 * 256 * 256 + 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 768,
-    "outproj_mlp_head1_fused": 2 * 256 * 256 + 2 * 256 * 1024 + 2 * 1024 * 256 + 2 * 256 * 1024,
     "gemm_head1": 2 * 256 * 1024,
     "gemm_head2": 2 * 1024 * 1024,
 }
@@ -47,15 +43,6 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 
 # padded token measured by the PMC passes committed under profiles/ ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950
 # correction applied) and the algorithmic bytes per token next to it.
 ROOFLINE_KERNELS = {
-    "outproj_mlp_inproj_fused": {
-        "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS,PRO> (out_proj -> +residual -> LayerNorm -> fc1 -> GELU -> fc2 -> +residual "
-                             "-> LayerNorm -> next block's in_proj, fp16x3)"},
-        "algorithmic_bpt": 1024 + 2 * 1024 + 3 * 1024 + 8,  # y in, residual stream in and out, in_proj output (fp32), statistics
-    },
-    "outproj_mlp_head1_fused": {
-        "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS_RELU_Q,PRO> (out_proj + last block's MLP + head linear1, fp16x3)"},
-        "algorithmic_bpt": 1024 + 2 * 1024 + 4 * 1024 + 12,
-    },
     "mlp_inproj_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS> (fc1 -> GELU -> fc2 -> +residual -> LayerNorm -> next block's in_proj, fp16x3)",
                    "traffic_bpt": (2 * 9884530.1 + 8404992.0) * 1024 / 2097152, "source": "profiles/r02_pmc_hbm_traffic.json"},

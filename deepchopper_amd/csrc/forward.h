@@ -54,12 +54,6 @@ struct GemmArgs {
   float w_inv_scale3;
   int N3, epi3;
   float* C3;                  // [N3][Tp]
-  // fused MLP, optional prologue GEMM: the Hyena operator's out_proj, x <- x + W0 . Y + bias0 (K -> K channels), run
-  // in front of fc1 inside the same kernel; mean / rstd are then not read (statistics come from the registers)
-  const unsigned short* Wp0;  // [2][K/8][K][8] fp16 h|l of out_proj^T * w_scale0, or nullptr
-  const float* bias0;         // [K]
-  float w_inv_scale0;
-  const float* Y;             // [K][Tp] gated output of the long convolution
 };
 
 struct FilterArgs {

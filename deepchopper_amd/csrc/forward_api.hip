@@ -61,7 +61,6 @@ struct dc_model {
   int* ovf_target = nullptr;  // caller-owned counter that replaces it (dc_model_set_overflow_target)
   float* u_table0 = nullptr;  // [vocab][3D] layer-0 in_proj(LayerNorm(emb[v])) (fp64 on the host)
   int mlp_fusion = 1;  // fp16x3: fc1 -> GELU -> fc2 in one kernel (dc_model_set_mlp_fusion)
-  int outproj_fusion = 0;  // ... with the Hyena operator's out_proj as its prologue GEMM (slower: off)
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
@@ -710,21 +709,16 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
     const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
     const bool fused_mlp = m->gemm_mode == 2 && sums && !no_mlp_fuse && m->mlp_fusion && L.Wq_fc2p && D == 256 &&
                            DI % 128 == 0 && DI <= 1024;
-    // out_proj as the fused MLP kernel's prologue GEMM: measured SLOWER than the separate launch (10.44 vs 8.94 + 1.38 ms
-    // per launch at 2 048 x 1 kb, profiles/r03_outproj_prologue_ab.json), so it is opt-in (DC_OUTPROJ_FUSE=1)
-    const bool fused_outproj = fused_mlp && (m->outproj_fusion || getenv("DC_OUTPROJ_FUSE") != nullptr);
-    if (!fused_outproj) {
-      if (sums && (rc = zero_stats())) return rc;
-      if ((rc = run_gemm(m, st, "gemm_outproj", WRef{L.Wt_out, L.Wp_out, L.Wq_out, L.is_out}, y, x, L.b_out, x, nullptr, false,
-                         sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, D, D)))
-        return rc;
-      if (!sums) {
-        ProfScope ps(m, st, "ln_stats");
-        if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
-      }
+    if (sums && (rc = zero_stats())) return rc;
+    if ((rc = run_gemm(m, st, "gemm_outproj", WRef{L.Wt_out, L.Wp_out, L.Wq_out, L.is_out}, y, x, L.b_out, x, nullptr, false,
+                       sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, D, D)))
+      return rc;
+    if (!sums) {
+      ProfScope ps(m, st, "ln_stats");
+      if ((rc = launch_ln_stats(st, x, D, Tp, c.ln_eps, mean, rstd))) return rc;
     }
     if (fused_mlp) {
-      // [out_proj ->] fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide
+      // fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide
       // activation stays in registers (fp16x3 only)
       GemmArgs g{};
       g.Wp = L.Wq_fc1;
@@ -748,12 +742,6 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       g.N = DI;
       g.Tp = Tp;
       g.gelu_tanh = c.gelu_tanh;
-      if (fused_outproj) {
-        g.Wp0 = L.Wq_out;
-        g.bias0 = L.b_out;
-        g.w_inv_scale0 = L.is_out;
-        g.Y = y;
-      }
       // chain: the GEMM that consumes LayerNorm(this block's output) runs inside the same kernel, its B operand
       // taken from the accumulator registers: the next block's in_proj, or the head's linear1 after the last block
       u_ready = false;
@@ -777,8 +765,7 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         g.q = qpad;
         head1_ready = true;
       }
-      ProfScope ps(m, st, g.Wp0 ? (g.Wp3 ? (g.epi3 == EPI_BIAS ? "outproj_mlp_inproj_fused" : "outproj_mlp_head1_fused") : "outproj_mlp_fused")
-                                : (g.Wp3 ? (g.epi3 == EPI_BIAS ? "mlp_inproj_fused" : "mlp_head1_fused") : "mlp_fused"));
+      ProfScope ps(m, st, g.Wp3 ? (g.epi3 == EPI_BIAS ? "mlp_inproj_fused" : "mlp_head1_fused") : "mlp_fused");
       if ((rc = launch_mlp_fused(st, g))) return rc;
     } else {
       u_ready = false;

@@ -878,11 +878,9 @@ int mlp_fused_perm16(int kappa) { return mlp_perm16(kappa); }
 #ifndef DC_M_ILV
 #define DC_M_ILV 1  // fused MLP: LDS-DMA pieces of the tile two steps ahead issued between the MFMA groups
 #endif
-// PRO: the Hyena operator's out_proj runs in front as a prologue GEMM (x <- x + W_out y + b_out) -- on its own that
-// GEMM is an HBM kernel (K = N = 256: 2 KiB/token in, 1 KiB out at 4.8 TB/s); here its output only exists as this
-// workgroup's token tile, the LayerNorm statistics come from the accumulator registers, and the separate launch, its
-// residual read and the statistics atomics disappear.
-template <bool TANH, int EPI3, bool PRO>  // EPI3: -1, or the epilogue of the fused third GEMM (EPI_BIAS / EPI_BIAS_RELU_Q)
+// (Round 3 also ran the Hyena operator's out_proj in front as a prologue GEMM of this kernel -- commit 41ee707: parity
+// green, 0.7 % slower than the separate launch, removed again; profiles/r03_outproj_prologue_ab.json.)
+template <bool TANH, int EPI3>  // EPI3: -1, or the epilogue of the fused third GEMM (EPI_BIAS / EPI_BIAS_RELU_Q)
 __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   typedef SplitMode<1> SM;
   typedef f16x8 svec;
@@ -905,8 +903,8 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   const int K8 = g.K >> 3, N8 = g.N >> 3;
 
   for (int j = tid; j < g.N; j += 64 * M_NW) s_b1[j] = g.bias[j];
-  float rs = 1.f, nm = 0.f;
-  if constexpr (!PRO) {
+  float rs, nm;
+  {
     const int64_t t = t_blk + t_w + i;
     float m = g.mean[t], r = g.rstd[t];  // sum / sum of squares over the K channels (fused statistics)
     m = m / (float)g.K;
@@ -923,8 +921,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   const uint32_t voff = lane * 16;
   // residual element of this lane's token in accumulator row `row_u + 4 h`: wave-uniform row base (scalar address
   // arithmetic) + one 32-bit per-lane element offset ((4 Tp + Tp) * 4 bytes < 2^32 for any batch that fits the HBM).
-  // Per-lane 64-bit row products instead were common-subexpression'd between the prologue and the epilogue and
-  // spilled (128 register pairs).
   const uint32_t xoff = (uint32_t)(4 * h) * (uint32_t)g.Tp + (uint32_t)(t_blk + t_w + i);
   auto x_at = [&](const float* xbase, int row_u) -> float { return (xbase + (int64_t)row_u * g.Tp)[xoff]; };
   // every use site launders its own copy of the base pointer through an empty asm (opaque SGPR pair), so the
@@ -974,136 +970,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
     __syncthreads();
     cur = cur + 1 == M_S ? 0 : cur + 1;
   };
-
-  if constexpr (PRO) {
-    // =============== prologue GEMM: x_new = x + W_out . y + b_out (K = 256 -> all 256 channels in acc2) ===============
-    // 16 steps of 16 k.  Tile image per step (32 KiB of a ring slot): W_out [plane][2 octets][256 outputs][8] fp16
-    // = 16 KiB, then the y tile [16 k][256 tokens] fp32 = 16 KiB; 32 DMA pieces, 4 per wave.  Shape of a fc2 step
-    // (8 output tiles x 3 MFMAs per wave) with the B fragment read from LDS and split like a fc1 step's.
-    constexpr int P_A0 = 2 * 2 * M_D * 16, P_T = M_D / 16;
-    auto issue0 = [&](int s0, int slot, int idx) {
-      const uint32_t base = lds0 + slot * M_SLOT;
-      const int q = wave + 8 * idx;
-      if (idx < 2) {
-        const int pl = q >> 3, o = (q >> 2) & 1, seg = q & 3;
-        const unsigned short* a0 = g.Wp0 + ((((int64_t)pl * K8 + 2 * s0 + o) * M_D + seg * 64) << 3);
-        glds16_s(a0, voff, base + ((pl * 2 + o) * M_D + seg * 64) * 16);
-      } else {
-        const int row = q - 16;
-        glds16_s(g.Y + (int64_t)(16 * s0 + row) * g.Tp + t_blk, voff, base + P_A0 + row * 1024);
-      }
-    };
-#pragma unroll
-    for (int idx = 0; idx < 4; ++idx) issue0(0, 0, idx);
-#pragma unroll
-    for (int idx = 0; idx < 4; ++idx) issue0(1, 1, idx);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s0 = 0; s0 < P_T; ++s0) {
-      const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
-      const bool more = s0 + 2 < P_T;
-      const uint32_t aB = lds0 + cur * M_SLOT + P_A0 + ((8 * h) * M_BT + t_w + i) * 4;
-      const uint32_t aW = lds0 + cur * M_SLOT + (h * M_D + i) * 16;
-      f32x2 xb[4];
-      static_for<4>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        xb[j] = lds_read2st64<4 * (2 * j), 4 * (2 * j + 1)>(aB);
-      });
-      u32x4 wf[2][2];  // [batch parity][plane]
-      auto load_w = [&](auto bc, u32x4 (&f)[2]) {
-        constexpr int b = decltype(bc)::value;
-        f[0] = lds_read_b128<(0 * M_D + b * 32) * 16>(aW);
-        f[1] = lds_read_b128<(2 * M_D + b * 32) * 16>(aW);
-      };
-      load_w(std::integral_constant<int, 0>{}, wf[0]);
-      lds_wait<2>(xb[0], xb[1], xb[2], xb[3]);
-      float yv[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        yv[2 * j] = xb[j][0];
-        yv[2 * j + 1] = xb[j][1];
-      }
-      svec ys[2];
-      SM::split_mx(yv, ys, mx);
-      static_for<8>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        if constexpr (b + 1 < 8) {
-          load_w(std::integral_constant<int, b + 1>{}, wf[(b + 1) & 1]);
-          if constexpr (b == 6) {  // barrier in front of the step's last two groups (see the fc1 steps)
-            lds_wait<0>(wf[0][0], wf[0][1], wf[1][0], wf[1][1]);
-            step_end(more ? 4 : 0);
-          } else {
-            lds_wait<2>(wf[b & 1][0], wf[b & 1][1]);
-          }
-        } else {
-          lds_wait<0>(wf[b & 1][0], wf[b & 1][1]);
-        }
-        const svec af[2] = {__builtin_bit_cast(svec, wf[b & 1][0]), __builtin_bit_cast(svec, wf[b & 1][1])};
-        acc2[b] = SM::mma(af, ys, acc2[b]);
-        if constexpr ((b & 1) == 1 && b < 6) {  // pieces 0..2 behind tiles 1, 3, 5; piece 3 in front of the barrier
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            issue0(s0 + 2, nslot, b >> 1);
-            if constexpr (b == 5) issue0(s0 + 2, nslot, 3);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-    }
-    // the ring is drained (the last two steps issued nothing).  x_new in the accumulator layout, its LayerNorm
-    // statistics from the registers (this wave holds all 256 channels of its 32 tokens on the two lane halves)
-    const float* xres = x_base();
-    float s_sum = 0.f, s_sq = 0.f;
-#pragma unroll
-    for (int tl = 0; tl < 8; ++tl) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int row0 = 32 * tl + 8 * gq + 4 * h;
-        const float4 b4 = *reinterpret_cast<const float4*>(g.bias0 + row0);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float xo = x_at(xres, 32 * tl + 8 * gq + r);
-          const float xn = fmaf(acc2[tl][4 * gq + r], g.w_inv_scale0, bb[r]) + xo;
-          acc2[tl][4 * gq + r] = xn;
-          s_sum += xn;
-          s_sq = fmaf(xn, xn, s_sq);
-        }
-      }
-    }
-    s_sum += __shfl_xor(s_sum, 32, 64);
-    s_sq += __shfl_xor(s_sq, 32, 64);
-    {
-      const float m = s_sum / (float)M_D;
-      const float var = fmaxf(s_sq / (float)M_D - m * m, 0.f);
-      rs = 1.0f / sqrtf(var + g.ln_eps);
-      nm = -m * rs;
-    }
-    // x_new -> HBM (it is fc1's B operand, streamed by LDS-DMA below, and the residual of this kernel's epilogue):
-    // row-wise 16-byte stores through the per-wave LDS patch
-    {
-      float* patch = reinterpret_cast<float*>(smem) + wave * 1024;
-      const int rr = lane >> 3, c4 = (lane & 7) * 4;
-      float* cst = g.C;
-      asm volatile("" : "+s"(cst));  // see x_base()
-#pragma unroll
-      for (int tl = 0; tl < 8; ++tl) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc2[tl][r];
-#pragma unroll
-        for (int p4 = 0; p4 < 4; ++p4) {
-          const float4 v = *reinterpret_cast<const float4*>(patch + (p4 * 8 + rr) * 32 + c4);
-          *reinterpret_cast<float4*>(cst + (int64_t)(32 * tl + p4 * 8 + rr) * g.Tp + t_blk + t_w + c4) = v;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[tl][r] = 0.f;
-      }
-    }
-    // stores complete + workgroup barrier: the tile is visible to this CU's LDS-DMA loads (one L1 per CU)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur = 0;
-  }
 
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1423,24 +1289,18 @@ int mlp_fused_perm(int k) { return (k & ~15) + mlp_perm16(k & 15); }
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
   DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
   DC_REQUIRE(g.K == M_D && g.N % M_HC == 0 && g.N <= 1024 && g.Tp % M_BT == 0, "fused MLP: d_model 256, d_inner <= 1024");
-  DC_REQUIRE(g.X == g.R && (g.Wp0 || (g.mean && g.rstd)) && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
+  DC_REQUIRE(g.X == g.R && g.mean && g.rstd && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
   if (g.Wp3)
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && g.N3 <= 1024 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
                "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
-  if (g.Wp0) DC_REQUIRE(g.bias0 && g.Y, "fused MLP: the out_proj prologue needs bias0 and Y");
-  auto launch = [&](auto tanh_c, auto epi_c, auto pro_c) {
-    hipLaunchKernelGGL((mlp_fused_kernel<decltype(tanh_c)::value, decltype(epi_c)::value, decltype(pro_c)::value>), grid, block,
-                       0, st, g);
-  };
-  auto by_pro = [&](auto tanh_c, auto epi_c) {
-    if (g.Wp0) launch(tanh_c, epi_c, std::true_type{});
-    else launch(tanh_c, epi_c, std::false_type{});
+  auto launch = [&](auto tanh_c, auto epi_c) {
+    hipLaunchKernelGGL((mlp_fused_kernel<decltype(tanh_c)::value, decltype(epi_c)::value>), grid, block, 0, st, g);
   };
   auto by_epi = [&](auto tanh_c) {
-    if (!g.Wp3) by_pro(tanh_c, std::integral_constant<int, -1>{});
-    else if (g.epi3 == EPI_BIAS) by_pro(tanh_c, std::integral_constant<int, EPI_BIAS>{});
-    else by_pro(tanh_c, std::integral_constant<int, EPI_BIAS_RELU_Q>{});
+    if (!g.Wp3) launch(tanh_c, std::integral_constant<int, -1>{});
+    else if (g.epi3 == EPI_BIAS) launch(tanh_c, std::integral_constant<int, EPI_BIAS>{});
+    else launch(tanh_c, std::integral_constant<int, EPI_BIAS_RELU_Q>{});
   };
   if (g.gelu_tanh) by_epi(std::true_type{});
   else by_epi(std::false_type{});

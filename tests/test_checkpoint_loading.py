@@ -10,7 +10,7 @@ import pytest
 
 from deepchopper_amd import weights as W
 
-from . import hf_module_tree as T
+import hf_module_tree as T  # tests/ is on sys.path (rootdir conftest, no package)
 
 
 def small_cfg():

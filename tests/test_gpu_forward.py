@@ -334,7 +334,7 @@ def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
 
 AB_SWITCHES = [("DC_NO_HEAD_FUSE", "1"), ("DC_NO_FUSED_STATS", "1"), ("DC_NO_L0_TABLE", "1"), ("DC_NO_L0_GATHER", "1"),
                ("DC_NO_MLP_CHAIN", "1"), ("DC_NO_MLP_FUSE", "1"), ("DC_HYENA", "2"), ("DC_H3_ONE_LAUNCH", "1"),
-               ("DC_H3_CB16", "1"), ("DC_OUTPROJ_FUSE", "1")]
+               ("DC_H3_CB16", "1")]
 
 
 @pytest.mark.parametrize("name,value", AB_SWITCHES, ids=[n for n, _ in AB_SWITCHES])
