@@ -155,6 +155,7 @@ def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all"
         n_out += writer.chop_write_chunk(params, n, res["headers"], res["header_offsets"], res["name_len"], res["seq"],
                                          res["qual"], res["in_offsets"], res["pred_len"], res["n_intervals"],
                                          res["intervals"], res["n_keep"], res["keep"])
+        writer.mark()  # a chunk's records end their BGZF block: per-GPU parts can be spliced in input order
         n_reads += n
         if on_batch is not None:
             on_batch(res)
@@ -173,37 +174,86 @@ def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | Non
         raise ValueError("Invalid chop type")
     tmp = part_path or _temp_name(fq, output_prefix)
     try:
-        with BgzfWriter(tmp, threads=threads, level=level) as fh:
+        fh = BgzfWriter(tmp, threads=threads, level=level)
+        with fh:
             if chunks is None:
                 with FastqReader(fq, full_header=True) as rd:
                     n_reads, n_out = predict_chop_stream(pipe, rd.chunks(max_reads, max_tokens), fh, chop_type,
                                                          output_chopped_seqs)
             else:
                 n_reads, n_out = predict_chop_stream(pipe, chunks, fh, chop_type, output_chopped_seqs)
-        if part_path:
+        if part_path:  # the writer is closed: the chunk offsets are known
+            write_part_index(part_path, fh)
             return tmp, n_reads, n_out
         if n_reads == 0:
             raise ValueError(f"No valid records found in {fq}")
         final = _final_name(fq, output_prefix, n_reads, n_out)
         os.replace(tmp, final)
     except Exception:
-        if os.path.exists(tmp):
-            os.remove(tmp)
+        for f in (tmp, tmp + ".idx.npy"):
+            if os.path.exists(f):
+                os.remove(f)
         raise
     return final, n_reads, n_out
 
 
-def merge_bgzf_parts(parts: list[str], final: str) -> None:
-    """Concatenate per-rank BGZF outputs: a BGZF file is a series of independent gzip members, so the byte-wise
-    concatenation (each part's 28-byte EOF block is an empty member) is again a valid BGZF / gzip stream."""
-    with open(final + ".tmp", "wb") as out:
-        for p in parts:
-            with open(p, "rb") as fh:
-                while True:
-                    b = fh.read(8 << 20)
-                    if not b:
-                        break
-                    out.write(b)
-    os.replace(final + ".tmp", final)
+BGZF_EOF = bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def write_part_index(part_path: str, writer: BgzfWriter) -> None:
+    """Sidecar of a per-rank part (after the writer is closed): the file offset behind every chunk (writer.mark())
+    and, last, the number of bytes in front of the EOF block."""
+    np.save(part_path + ".idx.npy", np.concatenate([writer.mark_offsets, [writer.data_bytes]]).astype(np.int64))
+
+
+def remove_parts(parts: list[str]) -> None:
     for p in parts:
-        os.remove(p)
+        for f in (p, p + ".idx.npy"):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def merge_bgzf_parts(parts: list[str], final: str, interleaved: bool = False) -> None:
+    """Splice the per-rank BGZF parts of a multi-GPU `predict --chop` into ONE file in INPUT order (the reference's
+    chop streams the FASTQ in order, src/bin/predict.rs:275-316; SURVEY 8e: "the host concatenates per-read results
+    in input order").  Every part has a sidecar `<part>.idx.npy` = the file offset after each of its chunks (the writer
+    ends a BGZF block there) + the bytes in front of its EOF block.
+
+    interleaved=False: rank r held the r-th contiguous range of the input (byte-range / BGZF-block shards): the parts'
+    data follow each other rank by rank.  interleaved=True: chunk g of the input went to rank g % W as its (g // W)-th
+    chunk (one gzip stream has one entry point, so chunks are dealt round-robin): the pieces are taken chunk by chunk.
+    Either way the result is whole BGZF blocks + one EOF block -- for the dealt form byte-identical to the file one
+    GPU writes, because that writer ends its blocks at the same chunk boundaries."""
+    idx = [np.load(p + ".idx.npy") for p in parts]
+    W = len(parts)
+    fhs = [open(p, "rb") for p in parts]
+
+    def copy(out, r, a, b):
+        fhs[r].seek(a)
+        left = b - a
+        while left > 0:
+            buf = fhs[r].read(min(left, 8 << 20))
+            if not buf:
+                raise IOError(f"{parts[r]}: truncated part")
+            out.write(buf)
+            left -= len(buf)
+
+    try:
+        with open(final + ".tmp", "wb") as out:
+            if not interleaved:
+                for r in range(W):
+                    copy(out, r, 0, int(idx[r][-1]))
+            else:
+                n_chunks = [len(ix) - 1 for ix in idx]
+                total = sum(n_chunks)
+                if any(n_chunks[r] != (total - r + W - 1) // W for r in range(W)):
+                    raise ValueError(f"parts do not form a round-robin deal of {total} chunks over {W} ranks: {n_chunks}")
+                for g in range(total):
+                    r, j = g % W, g // W
+                    copy(out, r, int(idx[r][j - 1]) if j else 0, int(idx[r][j]))
+            out.write(BGZF_EOF)
+    finally:
+        for fh in fhs:
+            fh.close()
+    os.replace(final + ".tmp", final)
+    remove_parts(parts)

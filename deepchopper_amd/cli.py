@@ -1,8 +1,11 @@
 """`deepchopper predict` / `deepchopper chop` command line (deepchopper/cli.py:66-170) on the HIP hot path.
 
-    python -m deepchopper_amd.cli predict reads.fastq -g 1 -o predictions -b 12 -m /path/to/checkpoint
-    python -m deepchopper_amd.cli predict reads.fastq.gz -g 8 --chop -m /path/to/checkpoint     # fused predict -> chop
-    python -m deepchopper_amd.cli chop predictions/0 reads.fastq
+    deepchopper predict reads.fastq -g 1 -o predictions -b 12 -m /path/to/checkpoint
+    deepchopper predict reads.fastq.gz -g 8 --chop -m /path/to/checkpoint     # fused predict -> chop
+    deepchopper chop predictions/0 reads.fastq                                 # (= deepchopper-chop --pdt ... --fq ...)
+
+(`pip install -e .` installs the `deepchopper` and `deepchopper-chop` entry points of pyproject.toml -- the reference's
+`deepchopper = "deepchopper.cli:app"`, pyproject.toml:58; `python -m deepchopper_amd.cli ...` works without installing.)
 
 Flags and defaults are the reference's (`--gpus/-g 0`, `--output/-o predictions`, `--batch-size/-b 12`,
 `--workers/-w 0`, `--model/-m rna002`, `--limit-batches`, `--max-sample`, `--verbose/-v`).  Differences:
@@ -100,33 +103,69 @@ def _launch_workers(args, argv: list[str]) -> int:
     port = launcher.free_port()
     import subprocess
 
-    for r in range(world):
-        env = launcher.rank_env(r, world, port, share)
-        cmd = list(child)
+    parts = [f"{part_base}.rank{r}" for r in range(world)] if part_base else []
+    try:
+        for r in range(world):
+            env = launcher.rank_env(r, world, port, share)
+            cmd = list(child)
+            if feeder is not None:
+                cmd += ["--chunk-fd", str(feeder.read_fds[r])]
+            if part_base:
+                cmd += ["--part-path", parts[r]]
+            procs.append(subprocess.Popen(cmd, env=env, pass_fds=per_rank_fds[r] if per_rank_fds else (), stdout=subprocess.PIPE, text=True))
         if feeder is not None:
-            cmd += ["--chunk-fd", str(feeder.read_fds[r])]
-        if part_base:
-            cmd += ["--part-path", f"{part_base}.rank{r}"]
-        procs.append(subprocess.Popen(cmd, env=env, pass_fds=per_rank_fds[r] if per_rank_fds else (), stdout=subprocess.PIPE, text=True))
-    if feeder is not None:
-        feeder.start()
-    outs = launcher.wait_ranks(procs)
-    if feeder is not None:
-        feeder.join()
-    reports = [launcher.last_json_line(o) for o in outs]
-    n_reads = sum(r["reads"] for r in reports)
-    if n_reads == 0:
-        raise ValueError(f"No valid records found in {path}")
-    summary = {"gpus": world, "reads": n_reads, "batches": sum(r["batches"] for r in reports),
-               "per_rank_reads": [r["reads"] for r in reports]}
-    if args.chop:
-        n_out = sum(r["records"] for r in reports)
-        final = chop_mod._final_name(path, args.chop_output, n_reads, n_out)
-        chop_mod.merge_bgzf_parts([f"{part_base}.rank{r}" for r in range(world)], final)
-        summary.update({"records": n_out, "output": final})
-        print(final)
+            feeder.start()
+        outs = launcher.wait_ranks(procs)
+        if feeder is not None:
+            feeder.join()
+        reports = [launcher.last_json_line(o) for o in outs]
+        n_reads = sum(r["reads"] for r in reports)
+        if n_reads == 0:
+            raise ValueError(f"No valid records found in {path}")
+        summary = {"gpus": world, "reads": n_reads, "batches": sum(r["batches"] for r in reports),
+                   "per_rank_reads": [r["reads"] for r in reports]}
+        if args.chop:
+            n_out = sum(r["records"] for r in reports)
+            final = chop_mod._final_name(path, args.chop_output, n_reads, n_out)
+            # dealt chunks (one gzip stream / --max-sample) are spliced chunk by chunk, contiguous shards rank by rank:
+            # the output is in input order either way
+            chop_mod.merge_bgzf_parts(parts, final, interleaved=feeder is not None)
+            summary.update({"records": n_out, "output": final})
+            print(final)
+    finally:
+        chop_mod.remove_parts(parts)  # nothing left behind when a worker, the feeder or the merge failed
     logging.info("%s", json.dumps(summary))
     return 0
+
+
+def _merge_under_external_launcher(args, rank: int, world: int, part: str, parts: list[str], n_reads: int, n_records: int,
+                                   interleaved: bool) -> None:
+    """`--chop` under torch.distributed.run (no parent of ours to merge): the ranks meet on a gloo group -- control
+    plane only, a barrier and one gathered tuple -- and rank 0 splices the parts exactly as the self-launching parent
+    does.  Without this every rank would leave a partial file that looks complete."""
+    import torch.distributed as dist
+
+    from . import chop as chop_mod
+
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo")
+    try:
+        counts = [None] * world
+        dist.all_gather_object(counts, (n_reads, n_records))
+        if rank == 0:
+            tot_r, tot_o = sum(c[0] for c in counts), sum(c[1] for c in counts)
+            if tot_r == 0:
+                raise ValueError(f"No valid records found in {args.data_path}")
+            final = chop_mod._final_name(str(args.data_path), args.chop_output, tot_r, tot_o)
+            chop_mod.merge_bgzf_parts(parts, final, interleaved=interleaved)
+            print(final)
+        dist.barrier()
+    finally:
+        if rank == 0:
+            chop_mod.remove_parts(parts)
+        if own:
+            dist.destroy_process_group()
 
 
 def _predict(args, argv: list[str]) -> int:
@@ -173,9 +212,19 @@ def _predict(args, argv: list[str]) -> int:
             nonlocal n_batches
             n_batches += 1
 
-        if args.part_path:  # worker of a multi-GPU run: the parent concatenates the parts and names the result
+        if args.part_path:  # worker of a multi-GPU run: the parent splices the parts and names the result
             _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                  args.ocq, chunks=chunks, part_path=args.part_path)
+        elif world > 1:  # external launcher (torch.distributed.run): parts on a name all ranks can derive, rank 0 merges
+            from .chop import _temp_name
+
+            base = os.path.join(os.path.dirname(_temp_name(str(data_path), args.chop_output)),
+                                f".deepchopper_temp_job{os.environ.get('MASTER_PORT', '0')}.fq.gz")
+            parts = [f"{base}.rank{r}" for r in range(world)]
+            _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
+                                                 args.ocq, chunks=chunks, part_path=parts[rank])
+            dealt = check_compressed_type(str(data_path)) not in ("Uncompress", "Bgzip") or args.max_sample is not None
+            _merge_under_external_launcher(args, rank, world, parts[rank], parts, n_reads, n_records, dealt)
         else:
             final, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                      args.ocq, chunks=chunks)
@@ -215,7 +264,9 @@ def _add_chop_options(p, prefix_output: bool) -> None:
     p.add_argument("--max-process-intervals", type=int, default=4)
     p.add_argument("--min-read-length", type=int, default=20)
     p.add_argument("--chop-type", default="all", choices=["terminal", "internal", "all"])
-    p.add_argument("--ocq", action="store_true", help="output the chopped (adapter) segments only (src/bin/predict.rs:60-62)")
+    p.add_argument("--output-chopped", "--ocq", dest="ocq", action="store_true",
+                   help="output the chopped (adapter) segments only (deepchopper/cli.py:163 `--output-chopped`; "
+                        "`--ocq` is the chop binary's spelling, src/bin/predict.rs:60-62)")
     p.add_argument("--threads", "-t", type=int, default=2, help="BGZF compression workers for the output (smoothing itself runs on the GPU)")
     if prefix_output:
         p.add_argument("--output", "-o", default=None, help="Output prefix")
@@ -223,7 +274,10 @@ def _add_chop_options(p, prefix_output: bool) -> None:
 
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
+    from . import __version__
+
     ap = argparse.ArgumentParser(prog="deepchopper", description="DeepChopper (MI355X-native predict path)")
+    ap.add_argument("--version", "-V", action="version", version=f"DeepChopper Version: {__version__}")  # cli.py:204-208
     sub = ap.add_subparsers(dest="cmd", required=True)
     p = sub.add_parser("predict", help="DeepChopper: predict the given dataset")
     p.add_argument("data_path", help="Path to the dataset")
@@ -265,6 +319,41 @@ def main(argv=None) -> int:
         print(path)
         return 0
     return _predict(args, argv)
+
+
+def chop_main(argv=None) -> int:
+    """`deepchopper-chop`: the chop binary's own flag names (clap, src/bin/predict.rs:19-78) -- what the reference's
+    `deepchopper chop` shells out to (deepchopper/cli.py:177-195) -- on the same driver as `deepchopper chop`."""
+    from . import __version__
+
+    ap = argparse.ArgumentParser(prog="deepchopper-chop")
+    ap.add_argument("--version", "-V", action="version", version=f"deepchopper-chop {__version__}")
+    ap.add_argument("--pdt", action="append", required=True, metavar="predicts", help="path to the predicts")
+    ap.add_argument("--fq", required=True, help="path to the integrated fq file")
+    ap.add_argument("-t", "--threads", type=int, default=2)
+    ap.add_argument("-m", "--max-batch-size", type=int, default=None)
+    ap.add_argument("-s", "--smooth-window-size", type=int, default=21)
+    ap.add_argument("--mis", type=int, default=13, help="min_interval_size")
+    ap.add_argument("-a", "--approved-interval-number", type=int, default=20)
+    ap.add_argument("--mpi", type=int, default=4, help="max process intervals")
+    ap.add_argument("--mcr", type=int, default=20, help="min read length after chop")
+    ap.add_argument("--ocq", action="store_true", help="output chopped fq file only")
+    ap.add_argument("--ct", default="all", choices=["terminal", "internal", "all"], help="selected chopped type")
+    ap.add_argument("-o", "--output-prefix", default=None)
+    ap.add_argument("--chunk-size", type=int, default=10000)
+    ap.add_argument("-d", "--debug", action="count", default=0)
+    a = ap.parse_args(sys.argv[1:] if argv is None else argv)
+    if a.debug:
+        logging.basicConfig(level=logging.INFO if a.debug == 1 else logging.DEBUG, format="%(message)s")
+    from . import _lib
+    from .chop import chop
+    from .predict import SmoothParams
+
+    _lib.require_gpu()
+    sp = SmoothParams(window=a.smooth_window_size, min_interval=a.mis, approved=a.approved_interval_number,
+                      max_process_intervals=a.mpi, min_read_length_after_chop=a.mcr)
+    print(chop(a.pdt, a.fq, sp, a.ct, a.output_prefix, a.chunk_size, a.max_batch_size, a.threads, a.ocq))
+    return 0
 
 
 if __name__ == "__main__":

@@ -1038,6 +1038,16 @@ struct dc_bgzf_writer {
   bool stop = false;
   std::unique_ptr<Job> cur;
   bool io_failed = false;
+  // marks (dc_bgzf_mark): a mark ends the current block; its file offset is known once every block submitted before
+  // it has been written -- recorded by the writing thread, never waited for
+  int64_t written = 0;                 // bytes written to fp
+  uint64_t n_submitted = 0, n_written = 0;
+  std::vector<uint64_t> mark_block;    // blocks submitted before the mark
+  std::vector<int64_t> mark_offset;    // file offset of the mark (filled in order)
+
+  void settle_marks() {
+    while (mark_offset.size() < mark_block.size() && mark_block[mark_offset.size()] <= n_written) mark_offset.push_back(written);
+  }
 
   void worker() {
     z_stream zs;
@@ -1082,6 +1092,9 @@ struct dc_bgzf_writer {
         io_failed = true;
         return fail(DC_FQ_ERR_IO, "write failed: %s", strerror(errno));
       }
+      written += (int64_t)j->out.size();
+      ++n_written;
+      settle_marks();
     }
   }
 
@@ -1093,6 +1106,7 @@ struct dc_bgzf_writer {
       inflight.emplace_back(std::move(cur));
       todo.push_back(raw);
     }
+    ++n_submitted;
     cv_work.notify_one();
     cur.reset(new Job);
     cur->in.reserve(kBgzfIn);
@@ -1151,7 +1165,15 @@ int dc_bgzf_write_fastq(dc_bgzf_writer* w, int64_t n, const char* names, const i
   return 0;
 }
 
-int dc_bgzf_close(dc_bgzf_writer* w) {
+int dc_bgzf_mark(dc_bgzf_writer* w) {
+  if (!w) return fail(DC_FQ_ERR_ARG, "null writer");
+  int rc = w->submit();  // the bytes written so far end their block here (no-op when the block is empty)
+  w->mark_block.push_back(w->n_submitted);
+  w->settle_marks();
+  return rc;
+}
+
+int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes) {
   if (!w) return fail(DC_FQ_ERR_ARG, "null writer");
   int rc = w->submit();
   int rc2 = w->drain(true, 0);
@@ -1162,11 +1184,23 @@ int dc_bgzf_close(dc_bgzf_writer* w) {
   }
   w->cv_work.notify_all();
   for (auto& t : w->workers) t.join();
+  w->settle_marks();
+  if (!rc && w->mark_offset.size() != w->mark_block.size()) rc = fail(DC_FQ_ERR_IO, "BGZF writer lost track of a mark");
+  if (n_marks) *n_marks = (int64_t)w->mark_offset.size();
+  if (data_bytes) *data_bytes = w->written;  // everything in front of the EOF block
+  if (!rc && mark_offsets) {
+    if ((int64_t)w->mark_offset.size() > cap) rc = fail(DC_FQ_ERR_ARG, "mark buffer too small: %lld marks", (long long)w->mark_offset.size());
+    else if (!w->mark_offset.empty()) memcpy(mark_offsets, w->mark_offset.data(), w->mark_offset.size() * sizeof(int64_t));
+  }
   if (!rc && fwrite(kBgzfEof, 1, sizeof kBgzfEof, w->fp) != sizeof kBgzfEof) rc = fail(DC_FQ_ERR_IO, "write failed");
   if (fclose(w->fp) != 0 && !rc) rc = fail(DC_FQ_ERR_IO, "close failed: %s", strerror(errno));
   delete w;
   return rc;
 }
+
+int dc_bgzf_close(dc_bgzf_writer* w) { return dc_bgzf_close2(w, nullptr, 0, nullptr, nullptr); }
+
+int64_t dc_bgzf_mark_count(const dc_bgzf_writer* w) { return w ? (int64_t)w->mark_block.size() : -1; }
 
 }  // extern "C"
 

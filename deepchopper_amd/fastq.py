@@ -176,6 +176,8 @@ class BgzfWriter:
 
     def __init__(self, path: str, threads: int = 2, level: int = 6):
         self._h = C.c_void_p()
+        self.mark_offsets = np.zeros(0, np.int64)  # file offset of every mark(), known after close()
+        self.data_bytes = 0                         # bytes in front of the EOF block, known after close()
         _iolib.raise_for(_iolib.lib().dc_bgzf_open(os.fsencode(str(path)), max(1, int(threads)), level, C.byref(self._h)))
 
     def write(self, data: bytes) -> None:
@@ -209,10 +211,20 @@ class BgzfWriter:
             ptr(records_per_read, np.int32), C.byref(total)))
         return int(total.value)
 
+    def mark(self) -> None:
+        """End the current BGZF block here and remember the position (never waits for the compression workers);
+        `mark_offsets` holds the file offsets after close()."""
+        _iolib.raise_for(_iolib.lib().dc_bgzf_mark(self._h))
+
     def close(self) -> None:
         if self._h:
             h, self._h = self._h, C.c_void_p()
-            _iolib.raise_for(_iolib.lib().dc_bgzf_close(h))
+            n = int(_iolib.lib().dc_bgzf_mark_count(h))
+            marks = np.zeros(max(n, 1), np.int64)
+            got, data = C.c_int64(0), C.c_int64(0)
+            _iolib.raise_for(_iolib.lib().dc_bgzf_close2(h, marks.ctypes.data, n, C.byref(got), C.byref(data)))
+            self.mark_offsets = marks[: int(got.value)].copy()
+            self.data_bytes = int(data.value)
 
     def __enter__(self):
         return self

@@ -22,14 +22,18 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     from deepchopper_amd.launcher import PipeChunks
     from deepchopper_amd.fastq import BgzfWriter
+    from deepchopper_amd.chop import write_part_index
     fd, part = int(sys.argv[1]), sys.argv[2]
     n = 0
     names = []
-    with BgzfWriter(part, threads=1) as w:
+    w = BgzfWriter(part, threads=1 + int(os.environ["RANK"]))
+    with w:
         for c in PipeChunks(fd):
             n += c.n
             names += c.names()
-            w.write_chunk(c) if c._name_len is None else None
+            w.write_chunk(c)
+            w.mark()  # as predict_chop_stream does after every chunk
+    write_part_index(part, w)
     print("noise before the report")
     print(json.dumps({"rank": int(os.environ["RANK"]), "world": int(os.environ["WORLD_SIZE"]), "reads": n,
                       "first": names[0] if names else None, "local_rank": os.environ["LOCAL_RANK"],
@@ -88,14 +92,54 @@ def test_single_inflater_feeds_every_worker_and_parts_merge(tmp_path, world):
     assert [r["local_rank"] for r in reports] == (["0"] * 3 if world == 3 else ["0", "1"])
     assert all(r["master"] == "127.0.0.1" for r in reports)
     final = str(tmp_path / "merged.fq.gz")
-    merge_bgzf_parts(parts, final)
-    assert not any(os.path.exists(p) for p in parts)
-    merged = gzip.open(final, "rb").read()
-    # chunks were dealt round-robin: the merged file holds every record exactly once, rank by rank
-    recs = sorted(merged.split(b"@read_")[1:])
-    assert recs == sorted(text.split(b"@read_")[1:])
-    with FastqReader(final) as rd:  # and our own reader (BGZF with EOF blocks in the middle) reads it all
+    merge_bgzf_parts(parts, final, interleaved=True)
+    assert not any(os.path.exists(p) or os.path.exists(p + ".idx.npy") for p in parts)
+    # chunks were dealt round-robin and spliced back chunk by chunk: the merged file IS the input, in input order
+    assert gzip.open(final, "rb").read() == text
+    # ... and byte for byte the file ONE writer produces when it ends its blocks at the same chunk boundaries
+    single = str(tmp_path / "single.fq.gz")
+    with BgzfWriter(single, threads=2) as w, FastqReader(str(fq)) as rd:
+        for c in rd.chunks(4, 5000):
+            w.write_chunk(c)
+            w.mark()
+    assert open(final, "rb").read() == open(single, "rb").read()
+    with FastqReader(final) as rd:
         assert sum(c.n for c in rd.chunks()) == 61
+
+
+def test_contiguous_parts_merge_rank_by_rank_and_bad_deals_are_refused(tmp_path):
+    from deepchopper_amd.chop import remove_parts, write_part_index
+
+    seqs, quals, ids = synth.synth_reads_mixed(30, 60, 300, seed=4)
+    fq = tmp_path / "r.fq"
+    text = synth.to_fastq(seqs, quals, ids)
+    fq.write_bytes(text)
+    with FastqReader(str(fq)) as rd:
+        chunks = [c for c in (FastqReaderChunkCopy(c) for c in rd.chunks(4, 1 << 20))]
+    assert len(chunks) == 8
+    parts = []
+    for r, sl in enumerate((slice(0, 3), slice(3, 3), slice(3, 8))):  # rank 1 holds no read at all
+        parts.append(str(tmp_path / f"p{r}"))
+        w = BgzfWriter(parts[-1], threads=1)
+        with w:
+            for c in chunks[sl]:
+                w.write_chunk(c)
+                w.mark()
+        write_part_index(parts[-1], w)
+    with pytest.raises(ValueError, match="round-robin deal"):
+        merge_bgzf_parts(parts, str(tmp_path / "bad.gz"), interleaved=True)
+    assert all(os.path.exists(p) for p in parts)  # refused before anything was consumed
+    final = str(tmp_path / "ok.gz")
+    merge_bgzf_parts(parts, final)
+    assert gzip.open(final, "rb").read() == text and not os.path.exists(parts[0])
+    remove_parts(parts)  # idempotent
+
+
+def FastqReaderChunkCopy(c):
+    from deepchopper_amd.fastq import FastqChunk
+
+    return FastqChunk(c.n, c.seq.copy(), c.qual.copy(), c.offsets.copy(), c._names.copy(), c._name_offsets.copy(),
+                      None if c._name_len is None else c._name_len.copy())
 
 
 def test_failed_worker_is_reported(tmp_path):
