@@ -109,14 +109,12 @@ def self_launch(args) -> None:
     """`python bench.py --gpus N` without a launcher: start N workers (one per GPU, the environment
     torch.distributed.run would give them), let them run the normal N-rank path (barrier, max over ranks) and
     print rank 0's line.  DC_BENCH_SHARE_GPU=1 rehearses this on a one-GPU box: every worker uses device 0 and
-    the process group runs on gloo."""
+    the process group runs on gloo (the default anyway)."""
     from deepchopper_amd import launcher
 
     share = os.environ.get("DC_BENCH_SHARE_GPU") == "1"
-    extra = {"DC_BENCH_BACKEND": "gloo"} if share else {}
-    procs = launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, share_gpu=share,
-                                 extra_env=extra)
-    outs = launcher.wait_ranks(procs)
+    procs = launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, share_gpu=share)
+    outs = launcher.wait_ranks(procs, timeout=float(os.environ.get("DC_BENCH_TIMEOUT", "1800")))  # a hung rank ends the job
     line = launcher.last_json_line(outs[0])
     line["launcher"] = "self (one subprocess per GPU)"
     print(json.dumps(line))
@@ -187,25 +185,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # one rank per GPU; DC_BENCH_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the N>1 code
-    # path on a one-GPU box (ranks then share the device)
-    backend = os.environ.get("DC_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    # One rank per GPU.  The process group is control plane only -- a barrier and the max of one host scalar -- and
+    # BASELINE.json's north_star says "no RCCL": gloo is the default.  DC_BENCH_BACKEND=nccl runs the same two calls
+    # over RCCL.  The backend is fixed BEFORE init from the environment every rank shares, so ranks cannot disagree
+    # (a per-rank fallback after a failed init would leave some ranks on another group and the first barrier hanging).
+    backend = os.environ.get("DC_BENCH_BACKEND", "gloo")
+    if backend not in ("gloo", "nccl"):
+        raise SystemExit(f"DC_BENCH_BACKEND must be gloo or nccl, not {backend!r}")
+    n_dev = max(torch.cuda.device_count(), 1)
+    # fewer GPUs than ranks only when rehearsing the N > 1 code path on a one-GPU box (DC_BENCH_SHARE_GPU=1)
+    dev_index = local_rank % n_dev if os.environ.get("DC_BENCH_SHARE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-            except Exception as e:  # the group only carries the barrier and one scalar max: gloo does that as well
-                print(f"[bench] rank {rank}: RCCL process group failed ({type(e).__name__}: {e}); control plane on gloo",
-                      file=sys.stderr)
-                backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group(backend)
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10), **kw)
 
     from deepchopper_amd import ops, synth
     from deepchopper_amd.model import DeepChopper

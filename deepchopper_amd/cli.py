@@ -191,6 +191,8 @@ def _predict(args, argv: list[str]) -> int:
     _lib.require_gpu()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DC_SHARE_GPU") == "1":  # rehearsing N ranks on a box with fewer GPUs (tests): ranks share devices
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     model_name = HUB_NAMES.get(args.model.lower(), args.model)
     model = DeepChopper.from_pretrained(model_name)

@@ -157,7 +157,8 @@ class ParInflate {
   std::function<bool()> cancelled_;
   uint64_t total_bits_ = 0;
   int n_ = 0, next_ = 0, released_ = 0, window_ = 0;
-  bool stop_ = false;
+  std::atomic<bool> stop_{false};  // set by the destructor; scan() and decode() poll it so that speculative work past the
+                                   // end of a member (the range covers the rest of the file) is dropped promptly
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<uint64_t> starts_;
@@ -179,6 +180,7 @@ class ParInflate {
     if (limit_bit < last) last = limit_bit;
     unsigned tick = 0;
     for (uint64_t p = from_bit; p < last; ++p) {
+      if ((p & 0xFFFF) == 0 && stop_.load(std::memory_order_relaxed)) break;
       const uint8_t* b8 = origin_ + (p >> 3);
       const uint64_t b = load64(b8) >> (p & 7);  // >= 57 valid bits
       if ((b & 7) != 4) continue;                // BFINAL = 0, BTYPE = 2
@@ -198,7 +200,7 @@ class ParInflate {
       }
       if (kraft != 128) continue;
       if (probe->probe_text_block(origin_, p, end_, scratch.data(), TRIAL)) return p;
-      if ((++tick & 63) == 0 && cancelled_()) break;
+      if ((++tick & 63) == 0 && (stop_.load(std::memory_order_relaxed) || cancelled_())) break;
     }
     return total_bits_;
   }
@@ -241,7 +243,7 @@ class ParInflate {
       const dcio::FastInflate::Status st = inf.run_t<uint16_t>(out, c.sym.get() + cap, (uint64_t)n, stop_bit);
       n = (size_t)(out - c.sym.get());
       if (st == dcio::FastInflate::NEED_OUTPUT) {
-        if ((++tick & 3) == 0 && cancelled_()) { c.failed = true; return; }
+        if (stop_.load(std::memory_order_relaxed) || ((++tick & 3) == 0 && cancelled_())) { c.failed = true; return; }
         // far more output than expected (or no later start was found): end the chunk at the next block boundary,
         // the coordinator carries on from there
         if (n - 32768 > SOFT_MAX && stop_bit > inf.bit_pos()) stop_bit = inf.bit_pos();

@@ -2130,14 +2130,11 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 template <int MODE, bool TAB>
 static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
-  static bool attr_set = false;
-  if (!attr_set) {
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE, TAB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE, TAB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // per call: the attribute is per device (one process may drive several) and setting it is cheap
+  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE, TAB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE, TAB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
   if (max_P <= 32 && !cb16) {
     hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);

@@ -520,3 +520,51 @@ def test_bench_shape_batch_properties(env, n_reads, bp):
         assert [tuple(x) for x in iv[r, : niv[r]].tolist()] == ivs
         assert [tuple(x) for x in kp[r, : nkp[r]].tolist()] == o.generate_unmaped_intervals(ivs, bp)
     assert pipe.model.net.overflow() == 0
+
+
+@pytest.mark.parametrize("launch", ["self-2", "self-3", "torchrun-2"])
+def test_multi_rank_chop_output_is_in_input_order_and_byte_identical_to_one_gpu(gated, tmp_path, launch):
+    """`predict -g N --chop` on a plain .fastq.gz (one inflater deals the chunks round-robin) writes
+    the SAME FILE, byte for byte, as `-g 1` -- records in input order, no sorting -- whether the command starts its own
+    workers or runs under torch.distributed.run (the external launcher used to leave N partial files).
+    The ranks share this box's one GPU (DC_SHARE_GPU=1)."""
+    import gzip
+
+    from deepchopper_amd.weights import save_state_dict
+
+    sd, _ = gated
+    ckpt = tmp_path / "ckpt" / "model.safetensors"
+    save_state_dict(sd, str(ckpt))
+    reads = _designed_reads(np.random.default_rng(5)) * 3
+    reads = [(b"r%03d_" % k + h, s, q) for k, (h, s, q) in enumerate(reads)]
+    text = b"".join(b"@" + h + b"\n" + s + b"\n+\n" + q + b"\n" for h, s, q in reads)
+    fq = tmp_path / "reads.fastq.gz"
+    with gzip.open(fq, "wb") as fh:
+        fh.write(text)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["predict", str(fq), "--chop", "-m", str(ckpt.parent), "--max-reads", "7", "--max-tokens", "6000", "-t", "2"]
+
+    def run(cmd, out_prefix, extra_env=None):
+        envv = dict(os.environ, DC_SHARE_GPU="1", **(extra_env or {}))
+        proc = subprocess.run(cmd + ["--chop-output", str(out_prefix)], cwd=root, capture_output=True, text=True, timeout=600, env=envv)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        out = [l for l in proc.stdout.strip().splitlines() if l.endswith(".chop.fq.gz")]
+        assert len(out) == 1, proc.stdout
+        return out[0]
+
+    one = run([sys.executable, "-m", "deepchopper_amd.cli"] + common + ["-g", "1"], tmp_path / "one")
+    kind, n = launch.split("-")
+    if kind == "self":
+        many = run([sys.executable, "-m", "deepchopper_amd.cli"] + common + ["-g", n], tmp_path / "many")
+    else:
+        many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                    "--master-port", "29617", "-m", "deepchopper_amd.cli"] + common + ["-g", n], tmp_path / "many")
+    assert os.path.basename(one).split(".", 1)[1] == os.path.basename(many).split(".", 1)[1]  # same {n}pd.{m}record counts
+    a, b = open(one, "rb").read(), open(many, "rb").read()
+    assert gzip.decompress(a) == gzip.decompress(b)
+    assert a == b
+    names = [l[1:].split(b"|")[0].split(b" ")[0] for l in gzip.decompress(b).split(b"\n")[0::4] if l]
+    order = [h.split(b" ")[0] for h, _, _ in reads]
+    assert [x for i, x in enumerate(names) if i == 0 or names[i - 1] != x] == [x for x in order if x in set(names)]
+    left = [f for f in os.listdir(tmp_path) if f.startswith(".deepchopper_temp")]
+    assert left == [], left
