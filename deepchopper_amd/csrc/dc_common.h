@@ -68,4 +68,34 @@ __device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigne
   return base + inc - v;
 }
 
+// The same for a block of BS = 64 / 128 / 256 threads (BS / 64 waves).
+template <int BS>
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* scratch, unsigned* total) {
+  static_assert(BS % 64 == 0 && BS <= 256, "block of 1..4 waves");
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (BS == 64) {
+    if (total) *total = __shfl(inc, 63, 64);
+    return inc - v;
+  }
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  unsigned base = 0, sum = 0;
+#pragma unroll
+  for (int w = 0; w < BS / 64; ++w) {
+    unsigned t = scratch[w];
+    if (w < wave) base += t;
+    sum += t;
+  }
+  if (total) *total = sum;
+  __syncthreads();
+  return base + inc - v;
+}
+
 }  // namespace dc

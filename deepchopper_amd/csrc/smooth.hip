@@ -1,4 +1,4 @@
-// Smoothing / interval path (S0-S5) as a wavefront scan.  One 256-thread workgroup per read.
+// Smoothing / interval path (S0-S5) as a wavefront scan.  One workgroup of 64 / 128 / 256 threads per read.
 //
 // Labels are held as bit-vectors in LDS (one 64-bit word per wavefront ballot).  A windowed
 // majority needs the number of ones in [start, end); that is P(end) - P(start) with
@@ -40,21 +40,22 @@ struct SmoothArgs {
 };
 
 // exclusive scan of popcounts of `words[0..nw)` into pref[0..nw]; pref[nw] = total.
+template <int BS, int CAPW>
 __device__ __forceinline__ void word_prefix(const unsigned long long* words, int nw, unsigned* pref,
                                             unsigned* scratch) {
-  // 256 threads x 4 consecutive words = 1024 words max
-  const int w0 = threadIdx.x * 4;
-  unsigned c[4];
+  constexpr int WPT = (CAPW + BS - 1) / BS;  // consecutive words per thread
+  const int w0 = threadIdx.x * WPT;
+  unsigned c[WPT];
   unsigned tsum = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < WPT; ++j) {
     c[j] = (w0 + j < nw) ? (unsigned)__popcll(words[w0 + j]) : 0u;
     tsum += c[j];
   }
   unsigned total;
-  unsigned ex = block_exclusive_scan_256(tsum, scratch, &total);
+  unsigned ex = block_exclusive_scan<BS>(tsum, scratch, &total);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < WPT; ++j) {
     if (w0 + j < nw) pref[w0 + j] = ex;
     ex += c[j];
   }
@@ -88,12 +89,25 @@ __device__ __forceinline__ int run_start(const unsigned long long* words, int i)
   }
 }
 
-template <bool FROM_LOGITS>
-__global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
-  __shared__ unsigned long long s_raw[SM_MAX_WORDS];   // raw labels, later "kept run end" flags
-  __shared__ unsigned long long s_sm[SM_MAX_WORDS];    // smoothed labels
-  __shared__ unsigned s_pref[SM_MAX_WORDS + 1];
+// 16 label bits -> 16 bytes of 0 / 1
+__device__ __forceinline__ uint4 bits_to_bytes16(unsigned m) {
+  auto q = [](unsigned x) { return (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21); };
+  return make_uint4(q(m), q(m >> 4), q(m >> 8), q(m >> 12));
+}
+
+// BS threads per read, LDS bit-vectors of CAPW words.  Global traffic moves in chunks of 16 consecutive positions per
+// thread: 8 x 16-byte logit loads, one 16-byte store of raw labels, one of smoothed labels (round 3; one position per
+// lane meant 64-byte label stores per wave: 1.1 TB/s).  Short reads take the 64-thread form (<1 KiB of LDS, a "barrier"
+// is a wave-local no-op, 28 reads resident per CU; a capacity of 16 words made hipcc turn the single-trip chunk loops into
+// straight-line code with 197 VGPRs); the 256-thread form holds reads up to 65 536 bases.
+template <bool FROM_LOGITS, int BS, int CAPW>
+__global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
+  __shared__ unsigned long long s_raw[CAPW];   // raw labels, later "kept run end" flags
+  __shared__ unsigned long long s_sm[CAPW];    // smoothed labels
+  __shared__ unsigned s_pref[CAPW + 1];
   __shared__ unsigned s_scratch[8];
+  unsigned short* raw16 = reinterpret_cast<unsigned short*>(s_raw);  // chunk c = bits [16 (c & 3), +16) of word c >> 2
+  unsigned short* sm16 = reinterpret_cast<unsigned short*>(s_sm);
 
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
@@ -107,53 +121,115 @@ __global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
       n = (int)(a.in_offsets[r + 1] - a.in_offsets[r]);
       lb = a.labels + a.in_offsets[r];
     }
-    if (n > SM_MAX_LEN) n = SM_MAX_LEN;  // host rejects longer reads; defensive clamp
+    if (n > CAPW * 64) n = CAPW * 64;  // host rejects longer reads / picks a larger form; defensive clamp
     if (n < 0) n = 0;
     const int nw = (n + 63) >> 6;
     const int n_pad = nw << 6;
+    const int nch = n_pad >> 4;
     const int64_t out_off = a.out_offsets ? a.out_offsets[r] : 0;
 
     // ---- S0: argmax (first max wins) -> label bits ------------------------------------
-    for (int i = threadIdx.x; i < n_pad; i += 256) {
-      bool lab = false;
-      if (i < n) {
+    for (int c = threadIdx.x; c < nch; c += BS) {
+      const int p0 = 16 * c;
+      unsigned m = 0;
+      if (p0 + 16 <= n) {
         if (FROM_LOGITS) {
-          const float2 v = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)i);
-          lab = v.y > v.x;  // class 1 only if strictly larger: ties -> 0
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float4 v;
+            __builtin_memcpy(&v, lg + 2 * (int64_t)p0 + 4 * j, 16);
+            m |= (v.y > v.x ? 1u : 0u) << (2 * j);  // class 1 only if strictly larger: ties -> 0
+            m |= (v.w > v.z ? 1u : 0u) << (2 * j + 1);
+          }
         } else {
-          lab = lb[i] == 1;
+          uint4 v;
+          __builtin_memcpy(&v, lb + p0, 16);
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 16; ++k) m |= (((wv[k >> 2] >> (8 * (k & 3))) & 255u) == 1u ? 1u : 0u) << k;
         }
-        if (FROM_LOGITS && a.pred) a.pred[out_off + i] = lab ? 1 : 0;
+        if (FROM_LOGITS && a.pred) {
+          const uint4 o = bits_to_bytes16(m);
+          __builtin_memcpy(a.pred + out_off + p0, &o, 16);
+        }
+      } else {
+        for (int k = 0; k < 16 && p0 + k < n; ++k) {
+          bool lab;
+          if (FROM_LOGITS) {
+            const float2 v = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)(p0 + k));
+            lab = v.y > v.x;
+          } else {
+            lab = lb[p0 + k] == 1;
+          }
+          m |= (lab ? 1u : 0u) << k;
+          if (FROM_LOGITS && a.pred) a.pred[out_off + p0 + k] = lab ? 1 : 0;
+        }
       }
-      const unsigned long long m = __ballot(lab);
-      if (lane == 0) s_raw[i >> 6] = m;
+      raw16[c] = (unsigned short)m;
     }
     __syncthreads();
-    word_prefix(s_raw, nw, s_pref, s_scratch);
+    word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);
 
     // ---- S1: majority_voting (smooth/utils.rs:48-97) -----------------------------------
     const int w = a.window, h = w >> 1;
-    for (int i = threadIdx.x; i < n_pad; i += 256) {
-      bool sm = false;
-      if (i < n) {
-        int start = i - h < 0 ? 0 : i - h;
-        int end = i + h + 1 > n ? n : i + h + 1;
-        if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
-        const int ones = (int)(ones_before(s_raw, s_pref, end) - ones_before(s_raw, s_pref, start));
-        const int ln = end - start;
-        if (2 * ones > ln) sm = true;
-        else if (2 * ones < ln) sm = false;
-        else sm = bit_at(s_raw, i);
-        if (a.smooth) a.smooth[out_off + i] = sm ? 1 : 0;
+    for (int c = threadIdx.x; c < nch; c += BS) {
+      const int p0 = 16 * c;
+      unsigned m = 0;
+      if (w <= 33) {
+        // every window of the chunk lies inside positions [p0 - 32, p0 + 32): four 16-bit pieces of the bit-vector
+        const unsigned long long W = (unsigned long long)(c >= 2 ? raw16[c - 2] : 0) |
+                                     (unsigned long long)(c >= 1 ? raw16[c - 1] : 0) << 16 |
+                                     (unsigned long long)raw16[c] << 32 |
+                                     (unsigned long long)(c + 1 < nch ? raw16[c + 1] : 0) << 48;
+        const int base = p0 - 32;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int i = p0 + k;
+          if (i < n) {
+            int start = i - h < 0 ? 0 : i - h;
+            int end = i + h + 1 > n ? n : i + h + 1;
+            if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
+            const int ln = end - start;  // 1 .. 33
+            const unsigned long long msk = ((1ull << ln) - 1ull) << (start - base);  // 0 <= start - base <= 47
+            const int ones = __popcll(W & msk);
+            bool sm;
+            if (2 * ones > ln) sm = true;
+            else if (2 * ones < ln) sm = false;
+            else sm = (W >> (32 + k)) & 1ull;
+            if (sm) m |= 1u << k;
+          }
+        }
+      } else {
+        for (int k = 0; k < 16 && p0 + k < n; ++k) {
+          const int i = p0 + k;
+          int start = i - h < 0 ? 0 : i - h;
+          int end = i + h + 1 > n ? n : i + h + 1;
+          if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
+          const int ones = (int)(ones_before(s_raw, s_pref, end) - ones_before(s_raw, s_pref, start));
+          const int ln = end - start;
+          bool sm;
+          if (2 * ones > ln) sm = true;
+          else if (2 * ones < ln) sm = false;
+          else sm = bit_at(s_raw, i);
+          if (sm) m |= 1u << k;
+        }
       }
-      const unsigned long long m = __ballot(sm);
-      if (lane == 0) s_sm[i >> 6] = m;
+      sm16[c] = (unsigned short)m;
+      if (a.smooth) {
+        if (p0 + 16 <= n) {
+          const uint4 o = bits_to_bytes16(m);
+          __builtin_memcpy(a.smooth + out_off + p0, &o, 16);
+        } else {
+          for (int k = 0; k < 16 && p0 + k < n; ++k) a.smooth[out_off + p0 + k] = (m >> k) & 1u;
+        }
+      }
     }
     __syncthreads();
 
     // ---- S2 + S3: run ends -> (start, end) with the index-0 quirk -> length filter -----
     // flag word: bit i set iff a kept interval ends at i (inclusive end)
-    for (int i = threadIdx.x; i < n_pad; i += 256) {
+#pragma unroll 1
+    for (int i = threadIdx.x; i < n_pad; i += BS) {
       bool kept = false;
       if (i < n && bit_at(s_sm, i) && (i == n - 1 || !bit_at(s_sm, i + 1))) {
         int s = run_start(s_sm, i);
@@ -165,13 +241,14 @@ __global__ __launch_bounds__(256) void smooth_kernel(SmoothArgs a) {
       if (lane == 0) s_raw[i >> 6] = m;
     }
     __syncthreads();
-    word_prefix(s_raw, nw, s_pref, s_scratch);
+    word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);
     const int total = (int)s_pref[nw];
     const bool rejected = a.apply_approved_rule && total > a.approved;  // predict.rs:204-206
     const int n_out = rejected ? 0 : total;
     int32_t* iv = a.intervals + (int64_t)r * a.max_intervals * 2;
     if (!rejected) {
-      for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll 1
+      for (int i = threadIdx.x; i < n; i += BS) {
         if (bit_at(s_raw, i)) {
           const int rank = (int)ones_before(s_raw, s_pref, i);
           if (rank < a.max_intervals) {
@@ -261,10 +338,17 @@ static int launch_smooth(void* stream, SmoothArgs& a, bool from_logits) {
   DC_REQUIRE(a.intervals && a.n_intervals, "intervals / n_intervals must not be NULL");
   if ((a.window & 1) == 0) a.window += 1;  // smooth/utils.rs:50-54
   int grid = a.n_reads < 65535 ? a.n_reads : 65535;
-  if (from_logits)
-    hipLaunchKernelGGL(smooth_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+  // logits mode: no read is longer than its row, so the row stride picks the form; ragged label input (the `.pt`
+  // route's chop) has its lengths on the device only and takes the general form
+  const int64_t max_len = from_logits ? a.row_stride : SM_MAX_LEN;
+  if (from_logits && max_len <= 2048)
+    hipLaunchKernelGGL((smooth_kernel<true, 64, 32>), dim3(grid), dim3(64), 0, as_stream(stream), a);
+  else if (from_logits && max_len <= 4096)
+    hipLaunchKernelGGL((smooth_kernel<true, 128, 64>), dim3(grid), dim3(128), 0, as_stream(stream), a);
+  else if (from_logits)
+    hipLaunchKernelGGL((smooth_kernel<true, 256, SM_MAX_WORDS>), dim3(grid), dim3(256), 0, as_stream(stream), a);
   else
-    hipLaunchKernelGGL(smooth_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL((smooth_kernel<false, 256, SM_MAX_WORDS>), dim3(grid), dim3(256), 0, as_stream(stream), a);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -1,5 +1,5 @@
-// Tokenise kernels (T1-T5): byte work, HBM-bound.  One 256-thread workgroup per read; lanes walk
-// the read's bytes with unit stride so every wave access is one contiguous 64-byte segment.
+// Tokenise kernels (T1-T5): byte work, HBM-bound.  dc_tokenize_batch: one wave per read, 16 bases per lane and step
+// (16-byte accesses); the small helpers (normalize_seq, encode_qual) walk bytes with unit stride.
 #include "dc_common.h"
 
 namespace dc {
@@ -73,15 +73,33 @@ __global__ void encode_qual_kernel(const uint8_t* __restrict__ q, int64_t n, uin
   for (; i < n; i += stride) out[i] = uint8_t(q[i] - off);
 }
 
+// One WAVE per read, 16 bases per lane and step (round 3; the first version gave every lane one byte: 64-byte wave
+// accesses, 1.0 TB/s).  A lane loads 16 sequence and 16 quality bytes with one 16-byte access each (gfx950 runs with
+// unaligned access enabled: a read starts at an arbitrary byte of the packed FASTQ buffers) and stores 16 tokens /
+// labels (16 B) and 16 fp32 qualities (4 x 16 B).  Loads that would leave the buffer (first / last read of a batch)
+// and the partial chunk at the end of a row go through a byte-wise path.  Arithmetic is unchanged: exact integer sum
+// of squares -> sqrtf -> IEEE division per base.
+constexpr int TK_WAVES = 4;  // reads per 256-thread workgroup
+
+__device__ __forceinline__ uint32_t byte_of(const uint4& v, int k) {
+  const uint32_t w = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
+  return (w >> (8 * (k & 3))) & 255u;
+}
+
 template <typename IdT>
-__global__ __launch_bounds__(256) void tokenize_batch_kernel(
+__global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
     const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const int64_t* __restrict__ offsets,
     int n_reads, int max_length, uint8_t qual_offset, int64_t row_stride, int pad_left,
     IdT* __restrict__ ids, float* __restrict__ quals, int8_t* __restrict__ labels,
     int32_t* __restrict__ n_tokens, int32_t* __restrict__ status) {
-  __shared__ unsigned long long s_sumsq[4];
-  __shared__ unsigned s_flags;
-  for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+  __shared__ uint8_t s_tok[256];  // raw byte -> token id (0xFF = removed by normalize)
+  s_tok[threadIdx.x] = token_of_raw((uint8_t)threadIdx.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t total_bytes = offsets[n_reads];
+  const int64_t wave0 = (int64_t)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * TK_WAVES;
+  for (int64_t r = wave0; r < n_reads; r += n_waves) {
     const int64_t beg = offsets[r];
     const int64_t raw_len = offsets[r + 1] - beg;
     int st = 0;
@@ -92,63 +110,133 @@ __global__ __launch_bounds__(256) void tokenize_batch_kernel(
       st |= DC_READ_TRUNCATED;
     }
     const int64_t ntok = len + 1;
-    if (threadIdx.x == 0) s_flags = 0;
-    __syncthreads();
 
     // pass 1: exact integer sum of squares of the phred values (quals = phred ++ [0]).
     unsigned long long acc = 0;
     unsigned flags = 0;
-    for (int64_t i = threadIdx.x; i < len; i += 256) {
-      const uint8_t qb = qual[beg + i];
-      if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
-      const unsigned p = uint8_t(qb - qual_offset);
-      acc += (unsigned long long)(p * p);
+    for (int64_t i0 = 16 * (int64_t)lane; i0 < len; i0 += 16 * 64) {
+      if (i0 + 16 <= len) {
+        uint4 qv;
+        __builtin_memcpy(&qv, qual + beg + i0, 16);
+        unsigned s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const uint32_t qb = byte_of(qv, k);
+          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
+          const unsigned p = (qb - qual_offset) & 255u;
+          s += p * p;  // 16 x 255^2 < 2^32
+        }
+        acc += s;
+      } else {
+        for (int64_t i = i0; i < len; ++i) {
+          const uint8_t qb = qual[beg + i];
+          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
+          const unsigned p = uint8_t(qb - qual_offset);
+          acc += (unsigned long long)(p * p);
+        }
+      }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) s_sumsq[threadIdx.x >> 6] = acc;
-    if (flags) atomicOr(&s_flags, flags);
-    __syncthreads();
-    const unsigned long long sumsq = s_sumsq[0] + s_sumsq[1] + s_sumsq[2] + s_sumsq[3];
     // F.normalize(dim=0): x / max(||x||_2, 1e-12), fp32 (tokenizer.py:166).
-    const float nrm = fmaxf(sqrtf((float)sumsq), 1e-12f);  // correctly rounded (hipcc default)
+    const float nrm = fmaxf(sqrtf((float)acc), 1e-12f);  // correctly rounded (hipcc default)
 
     const int64_t pad = pad_left ? (row_stride - ntok) : 0;
-    IdT* id_row = ids + (int64_t)r * row_stride;
-    float* q_row = quals + (int64_t)r * row_stride;
-    int8_t* l_row = labels ? labels + (int64_t)r * row_stride : nullptr;
+    IdT* id_row = ids + r * row_stride;
+    float* q_row = quals + r * row_stride;
+    int8_t* l_row = labels ? labels + r * row_stride : nullptr;
 
     // pass 2: write the whole row: pad | tokens | [SEP] (| pad on the right when !pad_left)
-    for (int64_t c = threadIdx.x; c < row_stride; c += 256) {
-      const int64_t i = c - pad;
-      IdT tok = (IdT)DC_TOK_PAD;
-      float qv = 0.0f;
-      int8_t lab = (int8_t)DC_IGNORE_LABEL;
-      if (i >= 0 && i < len) {
-        const uint8_t t = token_of_raw(seq[beg + i]);
-        if (t == 0xFF) {
-          flags |= DC_READ_DROPPED_CHARS;
-          tok = (IdT)11;
-        } else {
-          tok = (IdT)t;
+    for (int64_t c0 = 16 * (int64_t)lane; c0 < row_stride; c0 += 16 * 64) {
+      const int64_t i0 = c0 - pad;  // source index of the chunk's first column
+      const bool any_src = i0 + 16 > 0 && i0 < len;
+      uint4 sv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
+      if (any_src) {
+        const int64_t a0 = beg + i0;
+        if (a0 >= 0 && a0 + 16 <= total_bytes) {  // bytes outside [0, len) belong to the neighbouring reads: masked below
+          __builtin_memcpy(&sv, seq + a0, 16);
+          __builtin_memcpy(&qv, qual + a0, 16);
+        } else {  // first / last read of the buffer: byte-wise, in bounds
+          uint32_t sw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0};
+          for (int k = 0; k < 16; ++k) {
+            const int64_t i = i0 + k;
+            if (i >= 0 && i < len) {
+              sw[k >> 2] |= (uint32_t)seq[beg + i] << (8 * (k & 3));
+              qw[k >> 2] |= (uint32_t)qual[beg + i] << (8 * (k & 3));
+            }
+          }
+          sv = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+          qv = make_uint4(qw[0], qw[1], qw[2], qw[3]);
         }
-        const float p = (float)uint8_t(qual[beg + i] - qual_offset);
-        qv = p / nrm;  // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
-        lab = 0;
-      } else if (i == len) {
-        tok = (IdT)DC_TOK_SEP;
       }
-      id_row[c] = tok;
-      q_row[c] = qv;
-      if (l_row) l_row[c] = lab;
+      uint32_t tok[16];
+      float qf[16];
+      uint32_t lab[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int64_t i = i0 + k;
+        uint32_t t = DC_TOK_PAD;
+        float q = 0.0f;
+        uint32_t l = (uint32_t)(uint8_t)DC_IGNORE_LABEL;
+        if (i >= 0 && i < len) {
+          t = s_tok[byte_of(sv, k)];
+          if (t == 0xFFu) {
+            flags |= DC_READ_DROPPED_CHARS;
+            t = 11;
+          }
+          const float p = (float)((byte_of(qv, k) - qual_offset) & 255u);
+          q = p / nrm;  // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+          l = 0;
+        } else if (i == len) {
+          t = DC_TOK_SEP;
+        }
+        tok[k] = t;
+        qf[k] = q;
+        lab[k] = l;
+      }
+      if (c0 + 16 <= row_stride) {
+        if (sizeof(IdT) == 1) {
+          uint4 o;
+          o.x = tok[0] | tok[1] << 8 | tok[2] << 16 | tok[3] << 24;
+          o.y = tok[4] | tok[5] << 8 | tok[6] << 16 | tok[7] << 24;
+          o.z = tok[8] | tok[9] << 8 | tok[10] << 16 | tok[11] << 24;
+          o.w = tok[12] | tok[13] << 8 | tok[14] << 16 | tok[15] << 24;
+          __builtin_memcpy(id_row + c0, &o, 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 16; k += 2) {
+            const ulonglong2 o = make_ulonglong2(tok[k], tok[k + 1]);
+            __builtin_memcpy(id_row + c0 + k, &o, 16);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const float4 o = make_float4(qf[k], qf[k + 1], qf[k + 2], qf[k + 3]);
+          __builtin_memcpy(q_row + c0 + k, &o, 16);
+        }
+        if (l_row) {
+          uint4 o;
+          o.x = lab[0] | lab[1] << 8 | lab[2] << 16 | lab[3] << 24;
+          o.y = lab[4] | lab[5] << 8 | lab[6] << 16 | lab[7] << 24;
+          o.z = lab[8] | lab[9] << 8 | lab[10] << 16 | lab[11] << 24;
+          o.w = lab[12] | lab[13] << 8 | lab[14] << 16 | lab[15] << 24;
+          __builtin_memcpy(l_row + c0, &o, 16);
+        }
+      } else {  // the row ends inside this chunk: the next row belongs to another wave
+        for (int k = 0; k < 16 && c0 + k < row_stride; ++k) {
+          id_row[c0 + k] = (IdT)tok[k];
+          q_row[c0 + k] = qf[k];
+          if (l_row) l_row[c0 + k] = (int8_t)lab[k];
+        }
+      }
     }
-    if (flags) atomicOr(&s_flags, flags);
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    // status flags of the read: OR over the wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) flags |= __shfl_xor(flags, d, 64);
+    if (lane == 0) {
       if (n_tokens) n_tokens[r] = (int32_t)ntok;
-      status[r] = st | (int)s_flags;
+      status[r] = st | (int)flags;
     }
-    __syncthreads();
   }
 }
 
@@ -190,7 +278,8 @@ extern "C" int dc_tokenize_batch(void* stream, const uint8_t* d_seq, const uint8
   DC_REQUIRE(max_length >= 2, "max_length must be >= 2");
   DC_REQUIRE(row_stride >= 1, "row_stride must be >= 1");
   DC_REQUIRE(qual_offset >= 0 && qual_offset < 256, "qual_offset out of range");
-  int grid = n_reads < 65535 ? n_reads : 65535;
+  int64_t blocks = ((int64_t)n_reads + TK_WAVES - 1) / TK_WAVES;
+  int grid = (int)(blocks < 65535 ? blocks : 65535);
   if (ids_i64) {
     hipLaunchKernelGGL(tokenize_batch_kernel<int64_t>, dim3(grid), dim3(256), 0, as_stream(stream), d_seq, d_qual,
                        d_offsets, n_reads, max_length, (uint8_t)qual_offset, row_stride, pad_left,
