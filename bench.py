@@ -93,16 +93,27 @@ def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
                 out[rid] = (p.prediction, p.smooth_label(21), p.smooth_and_select_intervals(21, 13, 20))
         return out
 
-    t0 = time.perf_counter()
-    res = run(range(12))
-    per12 = time.perf_counter() - t0
-    n_more = int(max(0, min(len(seqs) - 12, (budget_s - per12) / max(per12, 1e-3) * 12)) // 12 * 12)
+    # The thread count is part of the baseline: torch's default (every host core, 128 on the GPU box) is NOT the fastest
+    # setting for batches of 12 x 1 001 tokens (round 2 reported 7.3 reads/s on 128 threads, slower than the reference's
+    # own prose figure).  Probe 8 / 16 / 32 / all on one reference batch each and measure with the best.
+    ncpu = os.cpu_count() or 1
+    res = run(range(12))  # warm-up: first-touch allocations, filter materialisation in the oracle
+    probe = {}
+    for t in sorted({x for x in (8, 16, 32, ncpu) if x <= ncpu}):
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        run(range(12))
+        probe[t] = round(12 / (time.perf_counter() - t0), 3)
+    best = max(probe, key=probe.get)
+    torch.set_num_threads(best)
+    per12 = 12 / probe[best]
+    spent = sum(12 / v for v in probe.values())
+    n_more = int(max(12, min(len(seqs) - 12, (budget_s - spent) / max(per12, 1e-3) * 12)) // 12 * 12)
+    n_more = min(n_more, (len(seqs) - 12) // 12 * 12)
     t1 = time.perf_counter()
-    if n_more:
-        res.update(run(range(12, 12 + n_more)))
-    total = per12 + (time.perf_counter() - t1)
-    n = 12 + n_more
-    return n / total, n, torch.get_num_threads(), res
+    res.update(run(range(12, 12 + n_more)))
+    total = time.perf_counter() - t1
+    return n_more / total, 12 + n_more, best, res, probe
 
 
 def self_launch(args) -> None:
@@ -324,12 +335,16 @@ def main():
         f1 = None
         if world == 1 and args.cpu_seconds > 0:
             seq, qual, ids = host_first
-            n_s = min(B, 240)
+            n_s = min(B, 600)
             seqs = [seq[i].tobytes() for i in range(n_s)]
             quals = [qual[i].tobytes() for i in range(n_s)]
-            rate, n_done, cores, ref = cpu_baseline(seqs, quals, ids[:n_s], sd, args.cpu_seconds)
+            rate, n_done, cores, ref, probe = cpu_baseline(seqs, quals, ids[:n_s], sd, args.cpu_seconds)
             cpu = {"value": round(rate, 3), "unit": "reads/s", "cores": cores, "kind": "port",
-                   "sample": f"{n_done} of the same synthetic {L}-bp reads, oracle tokenise+forward(torch fp32, batch 12)+smooth"}
+                   "sample": f"{n_done - 12} of the same synthetic {L}-bp reads (after a 12-read warm-up and the thread probe), "
+                             f"oracle tokenise+forward(torch fp32, batch 12)+smooth",
+                   "thread_probe_reads_per_s": {str(k): v for k, v in probe.items()}, "host_cores": os.cpu_count(),
+                   "reference_prose_cpu_reads_per_s": [46, 139],  # docs/faq.md:78-80 (2-6 h per 1 M reads), context only
+                   "note": "CPU restatement (oracle/), not the reference binary: its backbone cannot be loaded here (SURVEY 8c)"}
             # per-base F1 of the GPU labels against the oracle's on the sampled reads (expected 1.0)
             res = step(0)
             torch.cuda.synchronize()

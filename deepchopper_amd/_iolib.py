@@ -31,7 +31,7 @@ _SIGNATURES = {
     "dc_bgzf_close": (C.c_int, [vp]),
     "dc_bgzf_mark": (C.c_int, [vp]),
     "dc_bgzf_mark_count": (C.c_int64, [vp]),
-    "dc_bgzf_close2": (C.c_int, [vp, vp, i64, vp, vp]),
+    "dc_bgzf_close2": (C.c_int, [vp, vp, i64, vp, vp, vp]),
     "dc_chop_write_chunk": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, vp,
                                       C.POINTER(i64)]),
 }

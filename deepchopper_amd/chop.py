@@ -22,6 +22,7 @@ from .fastq import BgzfWriter, FastqReader
 from .predict import SmoothParams
 
 CHOP_TYPES = ("terminal", "internal", "all")
+LAST_WRITER_STATS: dict = {}  # host-budget accounting of the last predict_chop() of this process
 
 
 def chop_params(sp: SmoothParams, chop_type: str = "all", output_chopped_seqs: bool = False) -> "_iolib.ChopParams":
@@ -182,6 +183,7 @@ def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | Non
                                                          output_chopped_seqs)
             else:
                 n_reads, n_out = predict_chop_stream(pipe, chunks, fh, chop_type, output_chopped_seqs)
+        LAST_WRITER_STATS.update({"deflate_cpu_s": fh.deflate_cpu_s, "bgzf_bytes": fh.data_bytes, "threads": threads})
         if part_path:  # the writer is closed: the chunk offsets are known
             write_part_index(part_path, fh)
             return tmp, n_reads, n_out

@@ -80,11 +80,25 @@ def _chunk_limits(args, world: int) -> tuple[int, int]:
     return args.batch_size // world, 1 << 30    # reference batches: per-device reads per step, left-padded
 
 
+def _process_accounting(t_start: float) -> dict:
+    """CPU seconds / wall seconds / peak RSS of this process: what the host-budget measurement of an N-rank run adds up
+    (tools/host_budget.py, profiles/r03_host_budget_8rank.json)."""
+    import resource
+    import time
+
+    ru = resource.getrusage(resource.RUSAGE_SELF)
+    return {"cpu_user_s": round(ru.ru_utime, 3), "cpu_sys_s": round(ru.ru_stime, 3), "wall_s": round(time.time() - t_start, 3),
+            "max_rss_mb": round(ru.ru_maxrss / 1024, 1)}
+
+
 def _launch_workers(args, argv: list[str]) -> int:
     """Parent of a self-launched multi-GPU run: never touches the GPU."""
     from . import chop as chop_mod
     from . import launcher
 
+    import time
+
+    t_start = time.time()
     world = args.gpus
     path = str(args.data_path)
     share = os.environ.get("DC_SHARE_GPU") == "1"
@@ -135,6 +149,10 @@ def _launch_workers(args, argv: list[str]) -> int:
     finally:
         chop_mod.remove_parts(parts)  # nothing left behind when a worker, the feeder or the merge failed
     logging.info("%s", json.dumps(summary))
+    if args.report_json:
+        with open(args.report_json, "w") as fh:
+            json.dump({**summary, "input": "single inflater + pipes" if feeder is not None else "byte-range shards",
+                       "parent": _process_accounting(t_start), "ranks": reports}, fh)
     return 0
 
 
@@ -182,6 +200,9 @@ def _predict(args, argv: list[str]) -> int:
     if args.gpus > 1 and world == 1:
         return _launch_workers(args, argv)  # before anything touches the GPU
 
+    import time
+
+    t_start = time.time()
     import torch
 
     from . import _lib
@@ -199,10 +220,12 @@ def _predict(args, argv: list[str]) -> int:
     pipe = PredictPipeline(model, smooth=_smooth_params(args))
     out_dir = Path(args.output or "predictions")
     max_reads, max_bases = _chunk_limits(args, world)
+    pipe_src = None
     if args.chunk_fd is not None:
         from .launcher import PipeChunks
 
-        chunks = iter(PipeChunks(args.chunk_fd))  # the parent is this node's single reader / inflater
+        pipe_src = PipeChunks(args.chunk_fd)  # the parent is this node's single reader / inflater
+        chunks = iter(pipe_src)
     else:
         chunks = rank_chunks(str(data_path), rank, world, max_reads, max_bases, args.max_sample, full_header=bool(args.chop))
     chunks = limit_batches(chunks, args.limit_batches)
@@ -254,8 +277,18 @@ def _predict(args, argv: list[str]) -> int:
     if n_reads == 0 and world == 1:
         raise ValueError(f"No valid records found in {data_path}")
     logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
+    report = {"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records, **_process_accounting(t_start)}
+    if pipe_src is not None:
+        report.update({"pipe_read_cpu_s": round(pipe_src.cpu_s, 3), "pipe_bytes": pipe_src.bytes})
+    if args.chop:
+        from .chop import LAST_WRITER_STATS
+
+        report.update({k: (round(v, 3) if isinstance(v, float) else v) for k, v in LAST_WRITER_STATS.items()})
     if os.environ.get("DC_SELF_LAUNCHED") == "1":
-        print(json.dumps({"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records}), flush=True)
+        print(json.dumps(report), flush=True)
+    elif args.report_json and world == 1:
+        with open(args.report_json, "w") as fh:
+            json.dump({"gpus": 1, "ranks": [report]}, fh)
     return 0
 
 
@@ -299,6 +332,7 @@ def main(argv=None) -> int:
     p.add_argument("--chop", action="store_true", help="fused predict -> chop: write the chopped reads as BGZF FASTQ, no .pt files")
     p.add_argument("--chop-output", default=None, help="output prefix of --chop (default: the FASTQ's stem, as deepchopper chop)")
     _add_chop_options(p, prefix_output=False)
+    p.add_argument("--report-json", default=None, help=argparse.SUPPRESS)          # host-budget accounting of the run
     p.add_argument("--chunk-fd", type=int, default=None, help=argparse.SUPPRESS)   # worker: chunks come from the parent
     p.add_argument("--part-path", default=None, help=argparse.SUPPRESS)            # worker: per-rank BGZF part
     c = sub.add_parser("chop", help="DeepChopper: chop the given predictions!")

@@ -24,6 +24,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -1044,6 +1045,7 @@ struct dc_bgzf_writer {
   // it has been written -- recorded by the writing thread, never waited for
   int64_t written = 0;                 // bytes written to fp
   uint64_t n_submitted = 0, n_written = 0;
+  double deflate_cpu_s = 0.0;          // CPU seconds the workers spent inside deflate (host-budget accounting)
   std::vector<uint64_t> mark_block;    // blocks submitted before the mark
   std::vector<int64_t> mark_offset;    // file offset of the mark (filled in order)
 
@@ -1064,11 +1066,15 @@ struct dc_bgzf_writer {
         j = todo.front();
         todo.pop_front();
       }
+      timespec c0, c1;
+      clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
       bool good = ok && bgzf_compress(zs, level, *j);
+      clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
       {
         std::lock_guard<std::mutex> lk(mu);
         j->failed = !good;
         j->done = true;
+        deflate_cpu_s += (double)(c1.tv_sec - c0.tv_sec) + 1e-9 * (double)(c1.tv_nsec - c0.tv_nsec);
       }
       cv_done.notify_all();
     }
@@ -1175,7 +1181,8 @@ int dc_bgzf_mark(dc_bgzf_writer* w) {
   return rc;
 }
 
-int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes) {
+int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes,
+                   double* deflate_cpu_seconds) {
   if (!w) return fail(DC_FQ_ERR_ARG, "null writer");
   int rc = w->submit();
   int rc2 = w->drain(true, 0);
@@ -1190,6 +1197,7 @@ int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_
   if (!rc && w->mark_offset.size() != w->mark_block.size()) rc = fail(DC_FQ_ERR_IO, "BGZF writer lost track of a mark");
   if (n_marks) *n_marks = (int64_t)w->mark_offset.size();
   if (data_bytes) *data_bytes = w->written;  // everything in front of the EOF block
+  if (deflate_cpu_seconds) *deflate_cpu_seconds = w->deflate_cpu_s;
   if (!rc && mark_offsets) {
     if ((int64_t)w->mark_offset.size() > cap) rc = fail(DC_FQ_ERR_ARG, "mark buffer too small: %lld marks", (long long)w->mark_offset.size());
     else if (!w->mark_offset.empty()) memcpy(mark_offsets, w->mark_offset.data(), w->mark_offset.size() * sizeof(int64_t));
@@ -1200,7 +1208,7 @@ int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_
   return rc;
 }
 
-int dc_bgzf_close(dc_bgzf_writer* w) { return dc_bgzf_close2(w, nullptr, 0, nullptr, nullptr); }
+int dc_bgzf_close(dc_bgzf_writer* w) { return dc_bgzf_close2(w, nullptr, 0, nullptr, nullptr, nullptr); }
 
 int64_t dc_bgzf_mark_count(const dc_bgzf_writer* w) { return w ? (int64_t)w->mark_block.size() : -1; }
 

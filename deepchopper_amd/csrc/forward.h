@@ -113,6 +113,11 @@ int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t k
                             const float* tw, float* spec);  // spec: [D][2^logm + 1] float2
 int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,
                      const float* spec);
+// reads of 16 385 .. 32 769 tokens: 2^15 complex points as 16 x 2048 (two kernels, one scratch round trip of
+// hyena_fft15_scratch_bytes(n_reads, D)); the filter spectrum comes from launch_hyena_fft_filter(.., logm = 15, ..)
+int64_t hyena_fft15_scratch_bytes(int n_reads, int D);
+int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float* tw, const float* spec,
+                       float* scratch);
 int hyena3_units(int kf_taps);  // 16-byte units per (plane, shift) copy of the bf16 filter planes
 int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
                          unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale);

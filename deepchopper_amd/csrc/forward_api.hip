@@ -36,7 +36,7 @@ struct LayerDev {
   unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
   unsigned short* kfq = nullptr;  // fp16 planes (2) of the per-channel scaled filter
   float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
-  float* kspec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 10..14
+  float* kspec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 10..15
 };
 
 struct ProfEvent {
@@ -64,11 +64,12 @@ struct dc_model {
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
-  bool kspec_valid[5] = {false, false, false, false, false};  // spectra match the materialised filters
+  bool kspec_valid[6] = {false, false, false, false, false, false};  // spectra match the materialised filters
   int fft_min_tokens = 2560;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
   // FFT buckets of the cached geometry: read lists by transform size
   int32_t* d_fft_reads = nullptr;
-  int fft_count[5] = {0, 0, 0, 0, 0}, fft_offset[5] = {0, 0, 0, 0, 0};
+  int fft_count[6] = {0, 0, 0, 0, 0, 0}, fft_offset[6] = {0, 0, 0, 0, 0, 0};  // logm 10..14 in LDS, 15 = the 16 x 2048 four-step form
+  DevBuf fft_scratch;               // 2^15-point form: one HBM round trip between its two kernels
   int max_P_mfma = 0;
   int n_groups_long = 0;            // leading groups with reads above 1 024 tokens (16-block chunks); the rest fit one 32-block chunk
   std::vector<void*> owned;  // every weight allocation
@@ -319,7 +320,7 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
 // Filter spectra of every layer for transforms of 2^logm complex points (built once per materialised filter).
 int ensure_fft_spectra(dc_model* m, hipStream_t st, int logm) {
   const int b = logm - 10;
-  DC_REQUIRE(b >= 0 && b < 5, "FFT size out of range");
+  DC_REQUIRE(b >= 0 && b < 6, "FFT size out of range");
   if (!m->fft_tw) {
     DC_HIP_CHECK(hipMalloc((void**)&m->fft_tw, (size_t)fft_twiddle_count() * 2 * sizeof(float)));
     int rc = launch_fft_twiddles(st, m->fft_tw);
@@ -447,17 +448,18 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
   const int64_t n_tb = Tp / 32;
 
-  // Long reads (more than fft_min_tokens tokens, up to 2^14) take the FFT long convolution, bucketed by transform
-  // size; the others form groups of 32 reads of similar length (longest first) for the block-Toeplitz kernel.
+  // Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by transform size: up to 2^14
+  // tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form; the others form groups
+  // of 32 reads of similar length (longest first) for the block-Toeplitz kernel.
   std::vector<int32_t> order(n_reads);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
-  std::vector<int32_t> fft_lists[5], mfma_order;
+  std::vector<int32_t> fft_lists[6], mfma_order;
   for (int j = 0; j < n_reads; ++j) {
     const int r = order[j], nt = h_ntok[r];
-    if (nt > m->fft_min_tokens && nt <= (1 << 14)) {
+    if (nt > m->fft_min_tokens && nt <= (1 << 15) + 1) {
       int logm = 10;
-      while ((1 << logm) < nt) ++logm;
+      while ((1 << logm) < nt && logm < 15) ++logm;  // 2^15 + 1 tokens still fit the 2^15 form (one tap added by hand)
       fft_lists[logm - 10].push_back(r);
     } else {
       mfma_order.push_back(r);
@@ -473,7 +475,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     maxP_mfma = std::max(maxP_mfma, nblk[mfma_order[j]]);
   }
   std::vector<int32_t> fft_reads;
-  for (int b = 0; b < 5; ++b) {
+  for (int b = 0; b < 6; ++b) {
     m->fft_offset[b] = (int)fft_reads.size();
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
@@ -597,8 +599,16 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
   if ((rc = ensure_workspace(m, m->Tp))) return rc;
   if ((rc = ensure_filters(m, st, (int64_t)m->max_P * 32))) return rc;
-  for (int b = 0; b < 5; ++b)
+  for (int b = 0; b < 6; ++b)
     if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
+  constexpr int kFft15Batch = 16;  // reads per launch pair of the 2^15 form: 64 MiB of scratch each
+  if (m->fft_count[5]) {
+    const size_t need = (size_t)hyena_fft15_scratch_bytes(std::min(m->fft_count[5], kFft15Batch), c.d_model);
+    if (m->fft_scratch.bytes < need) {
+      DC_HIP_CHECK(hipStreamSynchronize(st));
+      if ((rc = ensure(m->fft_scratch, need))) return rc;
+    }
+  }
 
   const int D = c.d_model, DI = c.d_inner, H = c.head_hidden;
   float* x = (float*)m->x.p;
@@ -703,6 +713,12 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         if (m->fft_count[b] == 0) continue;
         ProfScope pf(m, st, "hyena_fft");
         if ((rc = launch_hyena_fft(st, a, 10 + b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
+          return rc;
+      }
+      for (int r0 = 0; r0 < m->fft_count[5]; r0 += kFft15Batch) {  // 16 385 .. 32 769 tokens: 16 x 2048 four-step form
+        ProfScope pf(m, st, "hyena_fft15");
+        if ((rc = launch_hyena_fft15(st, a, m->d_fft_reads + m->fft_offset[5] + r0, std::min(kFft15Batch, m->fft_count[5] - r0),
+                                     m->fft_tw, L.kspec[5], (float*)m->fft_scratch.p)))
           return rc;
       }
     }

@@ -23,7 +23,7 @@ namespace dc {
 
 namespace {
 
-constexpr int FFT_TW_N = 32768;  // twiddle table: exp(-2 pi i n / 32768)
+constexpr int FFT_TW_N = 65536;  // twiddle table: exp(-2 pi i n / 65536) (the 2^15-point form needs the 2^16-th roots)
 
 __global__ __launch_bounds__(256) void fft_twiddle_kernel(float2* __restrict__ tw) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -430,6 +430,305 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Reads of 16 385 .. 32 769 tokens (the model's context is 32 768 bases + [SEP], deepchopper/models/llm/components.py:
+// 8-14): M = 2^15 complex points do not fit the LDS, so the transform is split once, M = 16 x 2048 (four-step FFT):
+//   forward   c[m], m = n2 + 2048 n1:   a_k1[n2] = sum_n1 c[n2 + 2048 n1] W16^(n1 k1)      (<= 9 non-zero terms: the
+//             b_k1[n2] = a_k1[n2] W_M^(n2 k1);   C[k1 + 16 k2] = FFT_2048(b_k1)[k2]          input fills half of M)
+//   product   pairs k <-> M - k of the packed real transform: rows k1 and 16 - k1 (rows 0 and 8 pair with themselves)
+//   inverse   R_k1[b] = FFT_2048(conj Y'[k1 + 16 k2])[b] W_M^(k1 b)   ->   scratch[k1][b]    (one HBM round trip)
+//             r[b + 2048 a] = sum_k1 R_k1[b] W16^(k1 a)                                     (second kernel, + output gate)
+// hyena_fft15_kernel: one workgroup per (read, channel, row pair): two 2048-point transforms side by side in LDS (the
+// in-LDS radix-16 code above, 128 threads each), everything between the input rows and the scratch rows in LDS.  The
+// gated input is recomputed by the 8 workgroups of a (read, channel) (L2 hits, ~40 instructions per sample pair).
+// The filter spectrum keeps taps 0 .. M-1; a read of exactly M + 1 = 32 769 tokens is missing the single product
+// k'[M] z[0] in y[M], which the second kernel adds.
+// ---------------------------------------------------------------------------------------------------
+constexpr int F15_LOGM = 15, F15_M = 1 << F15_LOGM, F15_N2 = 2048, F15_ROW = F15_N2 + F15_N2 / 16;  // padded row (float2)
+
+// short causal filter + gating helpers of one (read, channel) (the same arithmetic as hyena_fft_kernel's lambdas)
+template <bool TAB>
+struct GateSrc {
+  const float *ux0, *ux1, *uv;
+  const unsigned char* tok;
+  const float* s_tab;
+  int L, t_last;
+  float sw_[3][3], sb_[3];
+  struct Raw {
+    float2 lo, hi;
+  };
+  __device__ __forceinline__ void init(const HyenaArgs& a, int r, int c, const float* s_tab_) {
+    const int64_t toff = a.toff[r];
+    L = a.ntok[r];
+    t_last = L > 0 ? (L - 1) & ~1 : 0;
+    ux0 = a.u + (int64_t)c * a.Tp + toff;
+    ux1 = a.u + (int64_t)(a.D + c) * a.Tp + toff;
+    uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + toff;
+    tok = TAB ? a.tok + toff : nullptr;
+    s_tab = s_tab_;
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sw_[k3][j] = a.sw[(k3 * a.D + c) * 3 + j];
+      sb_[k3] = a.sb[k3 * a.D + c];
+    }
+  }
+  __device__ __forceinline__ Raw raw_load(const float* row, int t) const {
+    Raw r;
+    const int tc = t < t_last ? t : t_last;
+    const int tl = tc >= 2 ? tc - 2 : 0;
+    if (TAB) {
+      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + tc);
+      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + tl);
+      uint32_t ids = (t >= 2 ? lo16 : 0xFFFFu) | (hi16 << 16);
+      if (t + 1 >= L) ids |= 0xFF000000u;
+      if (t >= L) ids = 0xFFFFFFFFu;
+      r.lo = make_float2(__builtin_bit_cast(float, ids), 0.f);
+      r.hi = make_float2(0.f, 0.f);
+      return r;
+    }
+    const float2 lo = *reinterpret_cast<const float2*>(row + tl);
+    const float2 hi = *reinterpret_cast<const float2*>(row + tc);
+    const bool in = t < L;
+    r.lo = make_float2(in && t >= 2 ? lo.x : 0.f, in && t >= 2 ? lo.y : 0.f);
+    r.hi = make_float2(in ? hi.x : 0.f, in && t + 1 < L ? hi.y : 0.f);
+    return r;
+  }
+  __device__ __forceinline__ v2f sc_eval(int k3, const Raw& r) const {  // the filter's outputs at t, t + 1
+    v2f lo, hi;
+    if (TAB) {
+      const uint32_t ids = __builtin_bit_cast(uint32_t, r.lo.x);
+      auto val = [&](int byte) -> float {
+        const uint32_t id = (ids >> (8 * byte)) & 255u;
+        return s_tab[k3 * 17 + (id < 16u ? id : 16u)];
+      };
+      lo = v2f{val(0), val(1)};
+      hi = v2f{val(2), val(3)};
+    } else {
+      lo = V(r.lo);
+      hi = V(r.hi);
+    }
+    const v2f mid = v2f{lo.y, hi.x};
+    const v2f w0 = sw_[k3][0], w1 = sw_[k3][1], w2 = sw_[k3][2], bb = sb_[k3];
+    return vfma(w0, lo, vfma(w1, mid, vfma(w2, hi, bb)));
+  }
+  // gated input pair z[t], z[t+1] (t even), zero beyond the read
+  __device__ __forceinline__ v2f z_pair(int t) const {
+    const Raw r1 = raw_load(ux1, t);
+    const Raw rv = TAB ? r1 : raw_load(uv, t);
+    v2f z = sc_eval(1, r1) * sc_eval(2, rv);
+    if (t >= L) z = v2f{0.f, 0.f};
+    else if (t + 1 >= L) z.y = 0.f;
+    return z;
+  }
+};
+
+// rows of workgroup p (0..7): (0, 8) for p = 0, (p, 16 - p) otherwise
+__device__ __forceinline__ void f15_rows(int p, int& ka, int& kb) {
+  ka = p;
+  kb = p == 0 ? 8 : 16 - p;
+}
+
+// forward half shared by the operator and the filter-spectrum kernel: fills the two rows from `sample(m)` (complex point
+// m of the packed input, zero beyond n_points) and transforms them.  s0 / s1: padded rows; tid in [0, 256).
+template <class Sample>
+__device__ __forceinline__ void f15_forward_rows(float2* s0, float2* s1, int ka, int kb, int n_points, const float2* __restrict__ tw,
+                                                 int tid, Sample sample) {
+  const int n1_used = (n_points + F15_N2 - 1) / F15_N2;  // blocks of 2048 points that hold input (<= 9)
+  float2 w16a[9];                                        // W16^(n1 ka); row kb uses the conjugate (kb = 16 - ka) or (-1)^n1 (kb = 8)
+#pragma unroll
+  for (int n1 = 0; n1 < 9; ++n1) w16a[n1] = tw[((n1 * ka) & 15) * (FFT_TW_N / 16)];
+#pragma unroll 1
+  for (int j = 0; j < F15_N2 / 256; ++j) {
+    const int n2 = tid + 256 * j;
+    v2f acc_a = v2f{0.f, 0.f}, acc_b = v2f{0.f, 0.f};
+#pragma unroll
+    for (int n1 = 0; n1 < 9; ++n1) {
+      if (n1 < n1_used) {  // block-uniform
+        const v2f cpt = sample(n2 + F15_N2 * n1);
+        const v2f wa = V(w16a[n1]);
+        acc_a += vcmul(cpt, wa);
+        acc_b += ka == 0 ? ((n1 & 1) ? -cpt : cpt) : vcmul(cpt, vconj(wa));
+      }
+    }
+    // b_k1[n2] = a_k1[n2] W_M^(n2 k1)
+    const v2f ta = V(tw[((n2 * ka) & (F15_M - 1)) * (FFT_TW_N / F15_M)]);
+    const v2f tb = V(tw[((n2 * kb) & (F15_M - 1)) * (FFT_TW_N / F15_M)]);
+    s0[pad16(n2)] = F(vcmul(acc_a, ta));
+    s1[pad16(n2)] = F(vcmul(acc_b, tb));
+  }
+  __syncthreads();
+  fft_lds<11>(tid < 128 ? s0 : s1, tw, tid & 127);
+}
+
+template <bool TAB>
+__global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int32_t* __restrict__ reads, const float2* __restrict__ tw,
+                                                          const float2* __restrict__ spec, float2* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw15[];
+  float2* s0 = reinterpret_cast<float2*>(s_raw15);
+  float2* s1 = s0 + F15_ROW;
+  float* s_tab = reinterpret_cast<float*>(s1 + F15_ROW);
+  const int slot = blockIdx.x >> 3, p = blockIdx.x & 7;
+  const int r = reads[slot], c = blockIdx.y, tid = threadIdx.x;
+  if (TAB) {
+    if (tid < 3 * 17) {
+      const int k3 = tid / 17, id = tid - 17 * k3;
+      s_tab[tid] = id < a.vocab && id < 16 ? a.tab[(int64_t)id * 3 * a.D + k3 * a.D + c] : 0.f;
+    }
+    __syncthreads();
+  }
+  GateSrc<TAB> g;
+  g.init(a, r, c, s_tab);
+  int ka, kb;
+  f15_rows(p, ka, kb);
+  const int n_points = (g.L + 1) >> 1;  // complex points that hold input
+  f15_forward_rows(s0, s1, ka, kb, n_points < F15_M ? n_points : F15_M, tw, tid, [&](int m) -> v2f { return g.z_pair(2 * m); });
+
+  // ---- spectrum product + repacking, pair (k, M - k); results stored conjugated (IFFT = conj . FFT . conj) ----
+  const float2* K = spec + (int64_t)c * (F15_M + 1);
+  constexpr int TW2 = FFT_TW_N / (2 * F15_M);  // W_2M^k = tw[k * TW2]
+  auto product = [&](float2* pk, float2* pmk, int k) {  // *pk = C[k], *pmk = C[M - k], 0 < k < M / 2 or k == M / 2 (pk == pmk)
+    const v2f ck = V(*pk), cmk = V(*pmk);
+    const v2f kf = V(K[k]), kbk = V(K[F15_M - k]), wk = V(tw[k * TW2]);
+    const v2f half = 0.5f;
+    const v2f bc = vconj(cmk);
+    const v2f e = half * (ck + bc), d = half * (ck - bc);
+    const v2f wo = vcmul(wk, v2f{d.y, -d.x});
+    const v2f zk = e + wo, zmk = vconj(e - wo);
+    const v2f yk = vcmul(zk, kf), ymk = vcmul(zmk, kbk);
+    const v2f bq = vconj(ymk);
+    const v2f ye = half * (yk + bq), d2 = half * (yk - bq);
+    const v2f yo = vcmul(vconj(wk), d2);
+    const v2f cp = ye + v2f{-yo.y, yo.x};
+    const v2f cq = vconj(ye) + v2f{yo.y, yo.x};
+    *pk = F(vconj(cp));
+    if (pk != pmk) *pmk = F(vconj(cq));
+  };
+  if (p != 0) {  // row ka index k2  <->  row kb index 2047 - k2
+#pragma unroll 1
+    for (int j = 0; j < F15_N2 / 256; ++j) {
+      const int k2 = tid + 256 * j;
+      product(s0 + pad16(k2), s1 + pad16(F15_N2 - 1 - k2), ka + 16 * k2);
+    }
+  } else {
+    // row 0: k = 16 k2 <-> row 0 index 2048 - k2 (k2 = 1 .. 1023), the real pair k = 0 / M, the self-paired k = M / 2
+    // row 8: k = 8 + 16 k2 <-> row 8 index 2047 - k2 (k2 = 0 .. 1023)
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+      const int k2 = tid + 256 * j;  // 0 .. 1023
+      product(s1 + pad16(k2), s1 + pad16(F15_N2 - 1 - k2), 8 + 16 * k2);
+      if (k2 >= 1) product(s0 + pad16(k2), s0 + pad16(F15_N2 - k2), 16 * k2);
+    }
+    if (tid == 0) {
+      const float2 c0 = s0[pad16(0)];
+      const float y0 = (c0.x + c0.y) * K[0].x;       // Y[0]  (real)
+      const float ym = (c0.x - c0.y) * K[F15_M].x;   // Y[M]  (real)
+      s0[pad16(0)] = make_float2(0.5f * (y0 + ym), -0.5f * (y0 - ym));
+      product(s0 + pad16(F15_N2 / 2), s0 + pad16(F15_N2 / 2), F15_M / 2);
+    }
+  }
+  __syncthreads();
+  fft_lds<11>(tid < 128 ? s0 : s1, tw, tid & 127);
+
+  // ---- R_k1[b] W_M^(k1 b) -> scratch[slot][c][k1][b] ----
+  float2* out = scratch + ((int64_t)slot * a.D + c) * F15_M;
+#pragma unroll 1
+  for (int j = 0; j < F15_N2 / 256; ++j) {
+    const int b = tid + 256 * j;
+    const v2f ta = V(tw[((b * ka) & (F15_M - 1)) * (FFT_TW_N / F15_M)]);
+    const v2f tb = V(tw[((b * kb) & (F15_M - 1)) * (FFT_TW_N / F15_M)]);
+    out[ka * F15_N2 + b] = F(vcmul(V(s0[pad16(b)]), ta));
+    out[kb * F15_N2 + b] = F(vcmul(V(s1[pad16(b)]), tb));
+  }
+}
+
+// second kernel: r[b + 2048 a] = sum_k1 scratch[k1][b] W16^(k1 a); y[t] = conv[t] * shortconv(x0)[t]
+template <bool TAB>
+__global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
+                                                              const float2* __restrict__ scratch) {
+  __shared__ float s_tab[64];
+  const int slot = blockIdx.x >> 3, bblk = blockIdx.x & 7;
+  const int r = reads[slot], c = blockIdx.y, tid = threadIdx.x;
+  if (TAB) {
+    if (tid < 3 * 17) {
+      const int k3 = tid / 17, id = tid - 17 * k3;
+      s_tab[tid] = id < a.vocab && id < 16 ? a.tab[(int64_t)id * 3 * a.D + k3 * a.D + c] : 0.f;
+    }
+    __syncthreads();
+  }
+  GateSrc<TAB> g;
+  g.init(a, r, c, s_tab);
+  const int b = bblk * 256 + tid;
+  const float2* in = scratch + ((int64_t)slot * a.D + c) * F15_M + b;
+  float2 u[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) u[k1] = in[k1 * F15_N2];
+  dft_regs<16>(u);  // frequency a at position bitrev(a)
+  const float inv_m = 1.0f / (float)F15_M;
+  float* y = a.y + (int64_t)c * a.Tp + a.toff[r];
+  const int L = g.L;
+#pragma unroll
+  for (int aa = 0; aa < 9; ++aa) {  // t = 2 (b + 2048 aa) < 32 770
+    const int t = 2 * (b + F15_N2 * aa);
+    if (t < L) {
+      const v2f rv = V(u[bitrev(aa, 4)]);
+      v2f conv = rv * v2f{inv_m, -inv_m};
+      if (t == F15_M) {  // L = M + 1: the tap the M-tap spectrum leaves out, y[M] += k'[M] z[0]
+        const v2f z0 = g.z_pair(0);
+        conv.x = fmaf(a.kf[(int64_t)c * a.kf_stride + F15_M], z0.x, conv.x);
+      }
+      const v2f o = conv * g.sc_eval(0, g.raw_load(g.ux0, t));
+      if (t + 1 < L) *reinterpret_cast<float2*>(y + t) = F(o);
+      else y[t] = o.x;
+    }
+  }
+}
+
+// filter spectrum for the 2^15-point form: K[c][0 .. M] = rfft(kf[c][0 .. M), n = 2M)
+__global__ __launch_bounds__(256) void hyena_fft15_filter_kernel(const float* __restrict__ kf, int64_t kf_stride, int kf_taps,
+                                                                 const float2* __restrict__ tw, float2* __restrict__ spec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw15[];
+  float2* s0 = reinterpret_cast<float2*>(s_raw15);
+  float2* s1 = s0 + F15_ROW;
+  const int p = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const float* k = kf + (int64_t)c * kf_stride;
+  int ka, kb;
+  f15_rows(p, ka, kb);
+  const int taps = kf_taps < F15_M ? kf_taps : F15_M;
+  f15_forward_rows(s0, s1, ka, kb, (taps + 1) >> 1, tw, tid, [&](int m) -> v2f {
+    const int t = 2 * m;
+    return v2f{t < taps ? k[t] : 0.f, t + 1 < taps ? k[t + 1] : 0.f};
+  });
+  float2* out = spec + (int64_t)c * (F15_M + 1);
+  constexpr int TW2 = FFT_TW_N / (2 * F15_M);
+  auto unpack = [&](const float2* pk, const float2* pmk, int kk) {
+    float2 zk, zmk;
+    unpack_pair<F15_LOGM>(*pk, *pmk, tw[kk * TW2], zk, zmk);
+    out[kk] = zk;
+    out[F15_M - kk] = zmk;
+  };
+  if (p != 0) {
+    for (int j = 0; j < F15_N2 / 256; ++j) {
+      const int k2 = tid + 256 * j;
+      unpack(s0 + pad16(k2), s1 + pad16(F15_N2 - 1 - k2), ka + 16 * k2);
+    }
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      const int k2 = tid + 256 * j;
+      unpack(s1 + pad16(k2), s1 + pad16(F15_N2 - 1 - k2), 8 + 16 * k2);
+      if (k2 >= 1) unpack(s0 + pad16(k2), s0 + pad16(F15_N2 - k2), 16 * k2);
+    }
+    if (tid == 0) {
+      const float2 c0 = s0[pad16(0)];
+      out[0] = make_float2(c0.x + c0.y, 0.f);
+      out[F15_M] = make_float2(c0.x - c0.y, 0.f);
+      unpack(s0 + pad16(F15_N2 / 2), s0 + pad16(F15_N2 / 2), F15_M / 2);
+    }
+  }
+}
+
+constexpr size_t f15_smem() { return (size_t)2 * F15_ROW * sizeof(float2) + 64 * sizeof(float); }
+
 template <int LOGM>
 constexpr size_t fft_smem() {
   return (size_t)((1 << LOGM) + (1 << LOGM) / 16) * sizeof(float2) + 64 * sizeof(float);
@@ -475,9 +774,38 @@ int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t k
     case 12: return launch_filter_t<12>(st, kf, kf_stride, kf_taps, D, t2, s2);
     case 13: return launch_filter_t<13>(st, kf, kf_stride, kf_taps, D, t2, s2);
     case 14: return launch_filter_t<14>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 15:
+      hipLaunchKernelGGL(hyena_fft15_filter_kernel, dim3(8, D), dim3(256), f15_smem(), st, kf, kf_stride, kf_taps, t2, s2);
+      DC_LAUNCH_CHECK();
+      return DC_OK;
   }
   set_error("FFT long convolution: unsupported size 2^%d", logm);
   return DC_ERR_UNSUPPORTED;
+}
+
+int64_t hyena_fft15_scratch_bytes(int n_reads, int D) { return (int64_t)n_reads * D * F15_M * (int64_t)sizeof(float2); }
+
+int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float* tw, const float* spec,
+                       float* scratch) {
+  if (n_reads <= 0) return DC_OK;
+  DC_REQUIRE(a.ntok && a.toff && a.u && a.y && a.sw && a.sb && a.kf && reads && tw && spec && scratch,
+             "FFT long convolution (2^15): null argument");
+  // (tap 32 768 of a.kf is read only for a read of 32 769 tokens, whose own length made the host materialise it)
+  const float2* t2 = reinterpret_cast<const float2*>(tw);
+  const float2* s2 = reinterpret_cast<const float2*>(spec);
+  float2* sc = reinterpret_cast<float2*>(scratch);
+  const dim3 grid((unsigned)(8 * n_reads), (unsigned)a.D), block(256);
+  if (a.tok) {
+    hipLaunchKernelGGL(hyena_fft15_kernel<true>, grid, block, f15_smem(), st, a, reads, t2, s2, sc);
+    DC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hyena_fft15_out_kernel<true>, grid, block, 0, st, a, reads, (const float2*)sc);
+  } else {
+    hipLaunchKernelGGL(hyena_fft15_kernel<false>, grid, block, f15_smem(), st, a, reads, t2, s2, sc);
+    DC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hyena_fft15_out_kernel<false>, grid, block, 0, st, a, reads, (const float2*)sc);
+  }
+  DC_LAUNCH_CHECK();
+  return DC_OK;
 }
 
 int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,

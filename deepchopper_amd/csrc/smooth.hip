@@ -109,7 +109,6 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
   unsigned short* raw16 = reinterpret_cast<unsigned short*>(s_raw);  // chunk c = bits [16 (c & 3), +16) of word c >> 2
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(s_sm);
 
-  const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     int n;
     const float* lg = nullptr;
@@ -227,18 +226,24 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     __syncthreads();
 
     // ---- S2 + S3: run ends -> (start, end) with the index-0 quirk -> length filter -----
-    // flag word: bit i set iff a kept interval ends at i (inclusive end)
-#pragma unroll 1
-    for (int i = threadIdx.x; i < n_pad; i += BS) {
-      bool kept = false;
-      if (i < n && bit_at(s_sm, i) && (i == n - 1 || !bit_at(s_sm, i + 1))) {
+    // flag word: bit i set iff a kept interval ends at i (inclusive end).  Per chunk of 16 positions: run ends are the
+    // set bits whose successor is clear (positions >= n are clear) -- a handful per read, so only those walk back to
+    // their run's start
+    for (int c = threadIdx.x; c < nch; c += BS) {
+      const unsigned m = sm16[c];
+      const unsigned nxt = c + 1 < nch ? (sm16[c + 1] & 1u) : 0u;
+      unsigned ends = m & ~((m >> 1) | (nxt << 15));
+      unsigned kept = 0;
+      while (ends) {
+        const int k = __builtin_ctz(ends);
+        ends &= ends - 1;
+        const int i = 16 * c + k;
         int s = run_start(s_sm, i);
         const int e = i + 1;
         if (s == 0) s = 1;  // utils.rs:680-683: `start == 0` doubles as "no open run"
-        kept = (s < e) && (e - s >= a.min_interval);
+        if ((s < e) && (e - s >= a.min_interval)) kept |= 1u << k;
       }
-      const unsigned long long m = __ballot(kept);
-      if (lane == 0) s_raw[i >> 6] = m;
+      raw16[c] = (unsigned short)kept;
     }
     __syncthreads();
     word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);
@@ -247,9 +252,12 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     const int n_out = rejected ? 0 : total;
     int32_t* iv = a.intervals + (int64_t)r * a.max_intervals * 2;
     if (!rejected) {
-#pragma unroll 1
-      for (int i = threadIdx.x; i < n; i += BS) {
-        if (bit_at(s_raw, i)) {
+      for (int c = threadIdx.x; c < nch; c += BS) {
+        unsigned m = raw16[c];
+        while (m) {
+          const int k = __builtin_ctz(m);
+          m &= m - 1;
+          const int i = 16 * c + k;
           const int rank = (int)ones_before(s_raw, s_pref, i);
           if (rank < a.max_intervals) {
             int s = run_start(s_sm, i);

@@ -111,74 +111,86 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
     }
     const int64_t ntok = len + 1;
 
-    // pass 1: exact integer sum of squares of the phred values (quals = phred ++ [0]).
-    unsigned long long acc = 0;
+    // (32-bit indices inside a row: a tokenised read is shorter than max_length, rows are checked on the host)
+    const int len32 = (int)len, stride32 = (int)row_stride;
+    const int pad = pad_left ? stride32 - (int)ntok : 0;
+    IdT* id_row = ids + r * row_stride;
+    float* q_row = quals + r * row_stride;
+    int8_t* l_row = labels ? labels + r * row_stride : nullptr;
     unsigned flags = 0;
-    for (int64_t i0 = 16 * (int64_t)lane; i0 < len; i0 += 16 * 64) {
-      if (i0 + 16 <= len) {
-        uint4 qv;
-        __builtin_memcpy(&qv, qual + beg + i0, 16);
-        unsigned s = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const uint32_t qb = byte_of(qv, k);
-          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
-          const unsigned p = (qb - qual_offset) & 255u;
-          s += p * p;  // 16 x 255^2 < 2^32
-        }
-        acc += s;
-      } else {
-        for (int64_t i = i0; i < len; ++i) {
-          const uint8_t qb = qual[beg + i];
-          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
-          const unsigned p = uint8_t(qb - qual_offset);
-          acc += (unsigned long long)(p * p);
+
+    // 16 sequence / quality bytes for source indices [i0, i0 + 16): bytes of the neighbouring reads inside the window
+    // are loaded as they are (masked by the users); a window that leaves the packed buffers (first / last read of a
+    // batch) is read byte-wise
+    auto load16 = [&](const uint8_t* __restrict__ src, int i0) -> uint4 {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i0 + 16 > 0 && i0 < len32) {
+        const int64_t a0 = beg + i0;
+        if (a0 >= 0 && a0 + 16 <= total_bytes) {
+          __builtin_memcpy(&v, src + a0, 16);
+        } else {
+          uint32_t w[4] = {0, 0, 0, 0};
+          for (int k = 0; k < 16; ++k)
+            if (i0 + k >= 0 && i0 + k < len32) w[k >> 2] |= (uint32_t)src[beg + i0 + k] << (8 * (k & 3));
+          v = make_uint4(w[0], w[1], w[2], w[3]);
         }
       }
+      return v;
+    };
+    auto sumsq16 = [&](int i0, const uint4& qv) -> unsigned {  // over [i0, i0 + 16) /\ [0, len)
+      unsigned sacc = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t qb = byte_of(qv, k);
+        if ((unsigned)(i0 + k) < (unsigned)len32) {
+          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
+          const unsigned p = (qb - qual_offset) & 255u;
+          sacc += p * p;  // 16 x 255^2 < 2^32
+        }
+      }
+      return sacc;
+    };
+
+    // A row of at most 1 024 columns is one step of the wave: its chunk is requested up front and, when the row carries
+    // no left-pad shift, also is the lane's share of the sum of squares -- the read's bytes are fetched ONCE and the only
+    // dependent memory round trip is load -> reduce -> store.  Otherwise pass 1 walks the quality bytes on its own.
+    const bool one_step = stride32 <= 16 * 64;
+    uint4 sv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
+    if (one_step) {
+      sv = load16(seq, 16 * lane - pad);
+      qv = load16(qual, 16 * lane - pad);
+    }
+    // pass 1: exact integer sum of squares of the phred values (quals = phred ++ [0]).
+    unsigned long long acc = 0;
+    if (one_step && pad == 0) {
+      acc = sumsq16(16 * lane, qv);
+    } else {
+#pragma unroll 1
+      for (int i0 = 16 * lane; i0 < len32; i0 += 16 * 64) acc += sumsq16(i0, load16(qual, i0));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     // F.normalize(dim=0): x / max(||x||_2, 1e-12), fp32 (tokenizer.py:166).
     const float nrm = fmaxf(sqrtf((float)acc), 1e-12f);  // correctly rounded (hipcc default)
 
-    const int64_t pad = pad_left ? (row_stride - ntok) : 0;
-    IdT* id_row = ids + r * row_stride;
-    float* q_row = quals + r * row_stride;
-    int8_t* l_row = labels ? labels + r * row_stride : nullptr;
-
     // pass 2: write the whole row: pad | tokens | [SEP] (| pad on the right when !pad_left)
-    for (int64_t c0 = 16 * (int64_t)lane; c0 < row_stride; c0 += 16 * 64) {
-      const int64_t i0 = c0 - pad;  // source index of the chunk's first column
-      const bool any_src = i0 + 16 > 0 && i0 < len;
-      uint4 sv = make_uint4(0, 0, 0, 0), qv = make_uint4(0, 0, 0, 0);
-      if (any_src) {
-        const int64_t a0 = beg + i0;
-        if (a0 >= 0 && a0 + 16 <= total_bytes) {  // bytes outside [0, len) belong to the neighbouring reads: masked below
-          __builtin_memcpy(&sv, seq + a0, 16);
-          __builtin_memcpy(&qv, qual + a0, 16);
-        } else {  // first / last read of the buffer: byte-wise, in bounds
-          uint32_t sw[4] = {0, 0, 0, 0}, qw[4] = {0, 0, 0, 0};
-          for (int k = 0; k < 16; ++k) {
-            const int64_t i = i0 + k;
-            if (i >= 0 && i < len) {
-              sw[k >> 2] |= (uint32_t)seq[beg + i] << (8 * (k & 3));
-              qw[k >> 2] |= (uint32_t)qual[beg + i] << (8 * (k & 3));
-            }
-          }
-          sv = make_uint4(sw[0], sw[1], sw[2], sw[3]);
-          qv = make_uint4(qw[0], qw[1], qw[2], qw[3]);
-        }
+#pragma unroll 1
+    for (int c0 = 16 * lane; c0 < stride32; c0 += 16 * 64) {
+      const int i0 = c0 - pad;  // source index of the chunk's first column
+      if (!one_step) {
+        sv = load16(seq, i0);
+        qv = load16(qual, i0);
       }
       uint32_t tok[16];
       float qf[16];
       uint32_t lab[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int64_t i = i0 + k;
+        const int i = i0 + k;
         uint32_t t = DC_TOK_PAD;
         float q = 0.0f;
         uint32_t l = (uint32_t)(uint8_t)DC_IGNORE_LABEL;
-        if (i >= 0 && i < len) {
+        if ((unsigned)i < (unsigned)len32) {
           t = s_tok[byte_of(sv, k)];
           if (t == 0xFFu) {
             flags |= DC_READ_DROPPED_CHARS;
@@ -187,14 +199,14 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
           const float p = (float)((byte_of(qv, k) - qual_offset) & 255u);
           q = p / nrm;  // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
           l = 0;
-        } else if (i == len) {
+        } else if (i == len32) {
           t = DC_TOK_SEP;
         }
         tok[k] = t;
         qf[k] = q;
         lab[k] = l;
       }
-      if (c0 + 16 <= row_stride) {
+      if (c0 + 16 <= stride32) {
         if (sizeof(IdT) == 1) {
           uint4 o;
           o.x = tok[0] | tok[1] << 8 | tok[2] << 16 | tok[3] << 24;
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
           __builtin_memcpy(l_row + c0, &o, 16);
         }
       } else {  // the row ends inside this chunk: the next row belongs to another wave
-        for (int k = 0; k < 16 && c0 + k < row_stride; ++k) {
+        for (int k = 0; k < 16 && c0 + k < stride32; ++k) {
           id_row[c0 + k] = (IdT)tok[k];
           q_row[c0 + k] = qf[k];
           if (l_row) l_row[c0 + k] = (int8_t)lab[k];
@@ -276,7 +288,7 @@ extern "C" int dc_tokenize_batch(void* stream, const uint8_t* d_seq, const uint8
   if (n_reads <= 0) return DC_OK;
   DC_REQUIRE(d_seq && d_qual && d_offsets && d_input_ids && d_input_quals && d_status, "null pointer");
   DC_REQUIRE(max_length >= 2, "max_length must be >= 2");
-  DC_REQUIRE(row_stride >= 1, "row_stride must be >= 1");
+  DC_REQUIRE(row_stride >= 1 && row_stride < ((int64_t)1 << 31), "row_stride must be in [1, 2^31)");
   DC_REQUIRE(qual_offset >= 0 && qual_offset < 256, "qual_offset out of range");
   int64_t blocks = ((int64_t)n_reads + TK_WAVES - 1) / TK_WAVES;
   int grid = (int)(blocks < 65535 ? blocks : 65535);

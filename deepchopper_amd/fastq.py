@@ -178,6 +178,7 @@ class BgzfWriter:
         self._h = C.c_void_p()
         self.mark_offsets = np.zeros(0, np.int64)  # file offset of every mark(), known after close()
         self.data_bytes = 0                         # bytes in front of the EOF block, known after close()
+        self.deflate_cpu_s = 0.0                    # CPU seconds of the compression workers, known after close()
         _iolib.raise_for(_iolib.lib().dc_bgzf_open(os.fsencode(str(path)), max(1, int(threads)), level, C.byref(self._h)))
 
     def write(self, data: bytes) -> None:
@@ -221,10 +222,11 @@ class BgzfWriter:
             h, self._h = self._h, C.c_void_p()
             n = int(_iolib.lib().dc_bgzf_mark_count(h))
             marks = np.zeros(max(n, 1), np.int64)
-            got, data = C.c_int64(0), C.c_int64(0)
-            _iolib.raise_for(_iolib.lib().dc_bgzf_close2(h, marks.ctypes.data, n, C.byref(got), C.byref(data)))
+            got, data, cpu = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+            _iolib.raise_for(_iolib.lib().dc_bgzf_close2(h, marks.ctypes.data, n, C.byref(got), C.byref(data), C.byref(cpu)))
             self.mark_offsets = marks[: int(got.value)].copy()
             self.data_bytes = int(data.value)
+            self.deflate_cpu_s = float(cpu.value)
 
     def __enter__(self):
         return self

@@ -172,12 +172,19 @@ class PipeChunks:
 
     def __init__(self, fd: int):
         self._fh = os.fdopen(fd, "rb", buffering=1 << 20)
+        self.cpu_s = 0.0   # CPU seconds of the consuming thread spent reading frames (host-budget accounting)
+        self.bytes = 0
 
     def __iter__(self) -> Iterator[FastqChunk]:
+        import time
+
         while True:
+            t0 = time.thread_time()
             c = read_chunk(self._fh)
+            self.cpu_s += time.thread_time() - t0
             if c is None:
                 return
+            self.bytes += 2 * int(c.offsets[c.n]) + int(c._name_offsets[c.n])
             yield c
 
     def close(self):

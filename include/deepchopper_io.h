@@ -114,11 +114,13 @@ int dc_bgzf_close(dc_bgzf_writer* w);
  * workers each write a BGZF part and the parent splices them in INPUT order).  dc_bgzf_mark ends the current block
  * and remembers the position; it never waits for the compression workers.  dc_bgzf_close2 = dc_bgzf_close that also
  * hands out the file offset of every mark (ascending; mark k = end of everything written before the k-th call) and
- * the number of data bytes in front of the 28-byte EOF block.  A part cut at its marks is a series of whole BGZF
- * blocks, so any concatenation of such pieces + one EOF block is a valid BGZF file. */
+ * the number of data bytes in front of the 28-byte EOF block (and the CPU seconds the compression workers spent in
+ * deflate: the host-budget accounting of an 8-rank run).  A part cut at its marks is a series of whole BGZF blocks, so
+ * any concatenation of such pieces + one EOF block is a valid BGZF file. */
 int dc_bgzf_mark(dc_bgzf_writer* w);
 int64_t dc_bgzf_mark_count(const dc_bgzf_writer* w);
-int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes);
+int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes,
+                   double* deflate_cpu_seconds);
 
 /* ---- chop stage of the fused predict -> chop flow ------------------------------------------------
  * One call per reader chunk: the gating of process_chunk (src/bin/predict.rs:130-192), the record

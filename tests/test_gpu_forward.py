@@ -234,19 +234,67 @@ def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     assert model.overflow() == 0
 
 
-@pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001), (1, 32769)])
+@pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001), (2, 20000), (1, 32768), (1, 32769)])
 def test_forward_long_reads_match_oracle(env, B, L):
     """BASELINE configs 3 and 4: 2 kb reads and reads up to 10 kb (several 32-block output chunks of the
     long-convolution kernel, filters longer than one LDS chunk); 32 769 tokens = the longest sequence the
-    tokenizer emits (max_len_single_sentence + [SEP]), i.e. the full 32k filter."""
+    tokenizer emits (max_len_single_sentence + [SEP]), i.e. the full 32k filter.  Reads above 16 384 tokens take the
+    four-step 2^15-point FFT (16 x 2048, csrc/hyena_fft.hip): asserted through the profile counters; 32 769 = 2^15 + 1
+    exercises the single tap that form adds by hand, 32 768 the case that does not need it."""
     torch, ops, sd, model = env
     from oracle import forward_ref as fr
 
     rng = np.random.default_rng(L)
     ids, q = _inputs(rng, B, L)
     ref = fr.forward(sd, ids, q).numpy()
-    out = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q)).cpu().numpy()
+    model.set_profiling(True)
+    model.profile_reset()
+    try:
+        out = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q)).cpu().numpy()
+        stages = model.profile()
+    finally:
+        model.set_profiling(False)
     _check(out, ref)
+    if model.gemm_mode != "f32" or True:  # the FFT forms serve every GEMM mode
+        want15 = 4 if L > 16384 else 0  # one launch pair per layer
+        assert stages.get("hyena_fft15", (0, 0))[1] == want15, stages
+        if 2560 < L <= 16384:
+            assert stages.get("hyena_fft", (0, 0))[1] == 4, stages
+
+
+def test_fft15_matches_toeplitz_and_mixes_with_other_sizes(hip_lib):
+    """The four-step form against the block-Toeplitz MFMA kernel of the same build (which serves these lengths when the
+    FFT is switched off), and a ragged batch that holds reads of the in-LDS sizes, the four-step size and the MFMA path
+    at once: every read equals its own single-read result."""
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+
+    sd = synthetic_state_dict(41)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    rng = np.random.default_rng(41)
+    L = 24001
+    ids, q = _inputs(rng, 1, L)
+    d_ids, d_q = ops.to_device(ids.astype(np.uint8)), ops.to_device(q)
+    try:
+        model.set_fft_threshold(1 << 20)
+        toep = model.forward(d_ids, d_q).cpu().numpy()
+        model.set_fft_threshold(2560)
+        fft = model.forward(d_ids, d_q).cpu().numpy()
+        assert np.abs(fft - toep).max() < 1e-4
+        lens = np.array([L, 700, 9000, 17000, 3000], np.int32)
+        ids2 = np.full((len(lens), L), 4, np.uint8)
+        q2 = np.zeros((len(lens), L), np.float32)
+        singles = []
+        for b, n in enumerate(lens):
+            i1, q1 = (ids, q) if b == 0 else _inputs(rng, 1, int(n))
+            ids2[b, L - n:], q2[b, L - n:] = i1[0], q1[0]
+            singles.append(model.forward(ops.to_device(i1.astype(np.uint8)), ops.to_device(q1)).cpu().numpy()[0])
+        first = (L - lens).astype(np.int32)
+        out = model.forward_ragged(ops.to_device(ids2), ops.to_device(q2), first, lens).cpu().numpy()
+        for b, n in enumerate(lens):
+            assert np.abs(out[b, L - n:] - singles[b]).max() < 2e-5, (b, n)
+    finally:
+        model.set_fft_threshold(2560)
 
 
 def test_forward_ragged_mixed_lengths_config4(env):
