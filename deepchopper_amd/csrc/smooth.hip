@@ -13,6 +13,7 @@ namespace dc {
 
 constexpr int SM_MAX_LEN = 65536;              // bases per read supported by the LDS bit-vectors
 constexpr int SM_MAX_WORDS = SM_MAX_LEN / 64;  // 1024
+constexpr int SM_LDS_IV = 32;                  // kept intervals mirrored in LDS (the default approved count is 20)
 
 struct SmoothArgs {
   // input (exactly one of logits / labels)
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
   __shared__ unsigned long long s_sm[CAPW];    // smoothed labels
   __shared__ unsigned s_pref[CAPW + 1];
   __shared__ unsigned s_scratch[8];
+  __shared__ int s_iv[2 * SM_LDS_IV];  // the first kept intervals, for the complement step (no global round trip)
   unsigned short* raw16 = reinterpret_cast<unsigned short*>(s_raw);  // chunk c = bits [16 (c & 3), +16) of word c >> 2
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(s_sm);
 
@@ -167,10 +169,10 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
       raw16[c] = (unsigned short)m;
     }
     __syncthreads();
-    word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);
+    const int w = a.window, h = w >> 1;
+    if (w > 33) word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);  // only the general window form counts through prefixes
 
     // ---- S1: majority_voting (smooth/utils.rs:48-97) -----------------------------------
-    const int w = a.window, h = w >> 1;
     for (int c = threadIdx.x; c < nch; c += BS) {
       const int p0 = 16 * c;
       unsigned m = 0;
@@ -264,6 +266,10 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
             if (s == 0) s = 1;
             iv[2 * rank] = s;
             iv[2 * rank + 1] = i + 1;
+            if (rank < SM_LDS_IV) {
+              s_iv[2 * rank] = s;
+              s_iv[2 * rank + 1] = i + 1;
+            }
           }
         }
       }
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
       } else {
         int cur = 0;
         for (int j = 0; j < m; ++j) {
-          const int s = iv[2 * j], e = iv[2 * j + 1];
+          const int s = j < SM_LDS_IV ? s_iv[2 * j] : iv[2 * j], e = j < SM_LDS_IV ? s_iv[2 * j + 1] : iv[2 * j + 1];
           if (cur < s) {
             kp[2 * cnt] = cur;
             kp[2 * cnt + 1] = s;

@@ -11,15 +11,17 @@ export TMPDIR=/tmp
 cd /tmp
 step() { echo "== $1" ; }
 step int-kernels-rocprof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_int -o int -- python3 $R/tools/bench_intkernels.py > $O/${TAG}_int_kernels_under_rocprof.json 2> $O/${TAG}_prof_int.err || echo "FAILED int-kernels-rocprof"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_int -o int -- python3 $R/tools/bench_intkernels.py > $O/${TAG}_int_kernels_under_rocprof.json 2> $O/${TAG}_prof_int.err || echo "FAILED int-kernels-rocprof"
+if [ "${SKIP_LONG:-0}" != "1" ]; then
 step long-reads
 timeout -k 10 400 python3 $R/tools/bench_long_reads.py > $O/${TAG}_long_reads_fft15.jsonl 2> $O/${TAG}_long_reads.err || echo "FAILED long-reads"
+fi
 step bench-rocprof
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-seconds 0 --e2e-reads 0 > $O/${TAG}_bench_under_rocprofv3.json 2> $O/${TAG}_prof_bench.err || echo "FAILED bench-rocprof"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-seconds 0 --e2e-reads 0 > $O/${TAG}_bench_under_rocprofv3.json 2> $O/${TAG}_prof_bench.err || echo "FAILED bench-rocprof"
 step pmc-fetch
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch -o f -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --no-profile > $O/${TAG}_pmc_fetch.json 2> $O/${TAG}_pmc_fetch.err || echo "FAILED pmc-fetch"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -o f -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --no-profile > $O/${TAG}_pmc_fetch.json 2> $O/${TAG}_pmc_fetch.err || echo "FAILED pmc-fetch"
 step pmc-write
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write -o w -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --no-profile > $O/${TAG}_pmc_write.json 2> $O/${TAG}_pmc_write.err || echo "FAILED pmc-write"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -o w -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --no-profile > $O/${TAG}_pmc_write.json 2> $O/${TAG}_pmc_write.err || echo "FAILED pmc-write"
 step bench-plain
 cd $R
 timeout -k 10 500 python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err || echo "FAILED bench-plain"
