@@ -130,81 +130,58 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     const int64_t out_off = a.out_offsets ? a.out_offsets[r] : 0;
 
     // ---- S0: argmax (first max wins) -> label bits ------------------------------------
-    if (FROM_LOGITS) {
-      // Coalesced: one wave instruction reads 1 KiB of consecutive logits (lane i: positions p, p + 1 with
-      // p = 128 jj + 2 i), the two compares land in SGPR pairs (= ballots of the even / odd positions) and scalar
-      // bit operations interleave them into the two 64-bit words of the bit-vector.  (Sixteen consecutive positions per
-      // lane, i.e. 128-byte lane strides, made every instruction touch 64 different cache lines and each line eight times.)
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      auto spread = [](unsigned long long x) -> unsigned long long {  // bit i of the low 32 -> bit 2 i
-        x &= 0xFFFFFFFFull;
-        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-        x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-        x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-        x = (x | (x << 2)) & 0x3333333333333333ull;
-        x = (x | (x << 1)) & 0x5555555555555555ull;
-        return x;
-      };
-      constexpr int UB = 8;  // loads in flight per wave before the first compare
-#pragma unroll 1
-      for (int j0 = 0; 128 * (wv + j0 * (BS / 64)) < n_pad; j0 += UB) {  // wave-uniform
-        float4 v[UB];
+    for (int c = threadIdx.x; c < nch; c += BS) {
+      const int p0 = 16 * c;
+      unsigned m = 0;
+      if (p0 + 16 <= n) {
+        if (FROM_LOGITS) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int p = 128 * (wv + (j0 + u) * (BS / 64)) + 2 * lane;
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p + 1 < n) {
-            __builtin_memcpy(&v[u], lg + 2 * (int64_t)p, 16);
-          } else if (p < n) {
-            const float2 t = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)p);
-            v[u].x = t.x;
-            v[u].y = t.y;
+          for (int j = 0; j < 8; ++j) {
+            float4 v;
+            __builtin_memcpy(&v, lg + 2 * (int64_t)p0 + 4 * j, 16);
+            m |= (v.y > v.x ? 1u : 0u) << (2 * j);  // class 1 only if strictly larger: ties -> 0
+            m |= (v.w > v.z ? 1u : 0u) << (2 * j + 1);
           }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int jj = wv + (j0 + u) * (BS / 64);
-          const int p = 128 * jj + 2 * lane;
-          const unsigned long long even = __ballot(p < n && v[u].y > v[u].x);  // class 1 only if strictly larger: ties -> 0
-          const unsigned long long odd = __ballot(p + 1 < n && v[u].w > v[u].z);
-          const unsigned long long w0 = spread(even) | (spread(odd) << 1);
-          const unsigned long long w1 = spread(even >> 32) | (spread(odd >> 32) << 1);
-          if (lane == 0 && 2 * jj < nw) {
-            s_raw[2 * jj] = w0;
-            if (2 * jj + 1 < nw) s_raw[2 * jj + 1] = w1;
-          }
-        }
-      }
-    } else {
-      for (int c = threadIdx.x; c < nch; c += BS) {
-        const int p0 = 16 * c;
-        unsigned m = 0;
-        if (p0 + 16 <= n) {
+        } else {
           uint4 v;
           __builtin_memcpy(&v, lb + p0, 16);
           const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int k = 0; k < 16; ++k) m |= (((wv[k >> 2] >> (8 * (k & 3))) & 255u) == 1u ? 1u : 0u) << k;
-        } else {
-          for (int k = 0; k < 16 && p0 + k < n; ++k) m |= (lb[p0 + k] == 1 ? 1u : 0u) << k;
         }
-        raw16[c] = (unsigned short)m;
+        if (FROM_LOGITS && a.pred) {
+          const uint4 o = bits_to_bytes16(m);
+          __builtin_memcpy(a.pred + out_off + p0, &o, 16);
+        }
+      } else {
+        for (int k = 0; k < 16 && p0 + k < n; ++k) {
+          bool lab;
+          if (FROM_LOGITS) {
+            const float2 v = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)(p0 + k));
+            lab = v.y > v.x;
+          } else {
+            lab = lb[p0 + k] == 1;
+          }
+          m |= (lab ? 1u : 0u) << k;
+          if (FROM_LOGITS && a.pred) a.pred[out_off + p0 + k] = lab ? 1 : 0;
+        }
       }
+      raw16[c] = (unsigned short)m;
     }
     __syncthreads();
     const int w = a.window, h = w >> 1;
-    if (w > 33) word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);  // only the general window form counts through prefixes
+    if (w > 31) word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);  // only the general window form counts through prefixes
 
     // ---- S1: majority_voting (smooth/utils.rs:48-97) -----------------------------------
     for (int c = threadIdx.x; c < nch; c += BS) {
       const int p0 = 16 * c;
       unsigned m = 0;
-      if (w <= 33) {
-        // every window of the chunk lies inside positions [p0 - 32, p0 + 32): four 16-bit pieces of the bit-vector
-        const unsigned long long W = (unsigned long long)(c >= 2 ? raw16[c - 2] : 0) |
-                                     (unsigned long long)(c >= 1 ? raw16[c - 1] : 0) << 16 |
-                                     (unsigned long long)raw16[c] << 32 |
-                                     (unsigned long long)(c + 1 < nch ? raw16[c + 1] : 0) << 48;
+      if (w <= 31) {
+        // every window of the chunk lies inside positions [p0 - 32, p0 + 32): four 16-bit pieces of the bit-vector, held
+        // as two 32-bit halves so that a window is one funnel shift (v_alignbit) + and + popcount, all full-rate 32-bit
+        // operations (64-bit shifts run at a quarter of the rate)
+        const unsigned lo = (c >= 2 ? (unsigned)raw16[c - 2] : 0u) | (c >= 1 ? (unsigned)raw16[c - 1] << 16 : 0u);
+        const unsigned hi = (unsigned)raw16[c] | (c + 1 < nch ? (unsigned)raw16[c + 1] << 16 : 0u);
         const int base = p0 - 32;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -213,13 +190,14 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
             int start = i - h < 0 ? 0 : i - h;
             int end = i + h + 1 > n ? n : i + h + 1;
             if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
-            const int ln = end - start;  // 1 .. 33
-            const unsigned long long msk = ((1ull << ln) - 1ull) << (start - base);  // 0 <= start - base <= 47
-            const int ones = __popcll(W & msk);
+            const int ln = end - start;                    // 1 .. 31
+            const unsigned sft = (unsigned)(start - base);  // 0 .. 47
+            const unsigned win = sft < 32u ? __builtin_amdgcn_alignbit(hi, lo, sft) : hi >> (sft - 32u);
+            const int ones = __popc(win & ((1u << ln) - 1u));
             bool sm;
             if (2 * ones > ln) sm = true;
             else if (2 * ones < ln) sm = false;
-            else sm = (W >> (32 + k)) & 1ull;
+            else sm = (hi >> k) & 1u;
             if (sm) m |= 1u << k;
           }
         }
@@ -239,15 +217,6 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
         }
       }
       sm16[c] = (unsigned short)m;
-      if (FROM_LOGITS && a.pred) {  // raw labels of the chunk, from the bit-vector
-        const unsigned rm = raw16[c];
-        if (p0 + 16 <= n) {
-          const uint4 o = bits_to_bytes16(rm);
-          __builtin_memcpy(a.pred + out_off + p0, &o, 16);
-        } else {
-          for (int k = 0; k < 16 && p0 + k < n; ++k) a.pred[out_off + p0 + k] = (rm >> k) & 1u;
-        }
-      }
       if (a.smooth) {
         if (p0 + 16 <= n) {
           const uint4 o = bits_to_bytes16(m);
