@@ -568,3 +568,53 @@ def test_multi_rank_chop_output_is_in_input_order_and_byte_identical_to_one_gpu(
     assert [x for i, x in enumerate(names) if i == 0 or names[i - 1] != x] == [x for x in order if x in set(names)]
     left = [f for f in os.listdir(tmp_path) if f.startswith(".deepchopper_temp")]
     assert left == [], left
+
+
+def test_pipeline_lanes_give_identical_results(env, tmp_path):
+    """`PredictPipeline(lanes=3)`: consecutive batches run on three HIP streams with a model handle (workspace) each.
+    Same kernels on disjoint data: every chunk's labels, smoothed labels, intervals, kept segments AND logits equal the
+    one-lane pipeline's bit for bit, in input order; `run_lanes` equals `run_device_batch` on the pieces; the fused
+    predict -> chop output is the same file."""
+    torch, sd, pipe = env
+    from deepchopper_amd import ops, synth
+    from deepchopper_amd.chop import predict_chop
+    from deepchopper_amd.fastq import FastqReader
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+
+    pipe3 = PredictPipeline(DeepChopper.from_state_dict(sd), lanes=3)
+    assert pipe3.lanes == 3 and pipe.lanes == 1
+    seqs, quals, ids = synth.synth_reads_mixed(70, 100, 2500, seed=23)
+    fq = tmp_path / "mixed.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+
+    def stream(p):
+        out = []
+        with FastqReader(str(fq)) as rd:
+            for res in p.predict_stream(rd.chunks(max_reads=9, cap_bases=20_000)):
+                out.append({k: np.array(res[k], copy=True) for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep", "offsets")}
+                           | {"names": list(res["names"]), "logits": res["device"]["logits"].cpu().numpy()})
+        return out
+
+    one, three = stream(pipe), stream(pipe3)
+    assert len(one) == len(three) >= 7 and [n for c in three for n in c["names"]] == ids
+    for a, b in zip(one, three):
+        assert a["names"] == b["names"]
+        for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep", "offsets", "logits"):
+            assert np.array_equal(a[k], b[k]), k
+    # run_lanes: three device batches at once == each of them alone
+    parts = []
+    for j in range(3):
+        sq, ql, _ = synth.synth_reads_fixed(5 + j, 300, seed=30 + j)
+        offs = np.arange(5 + j + 1, dtype=np.int64) * 300
+        parts.append((ops.to_device(sq.reshape(-1)), ops.to_device(ql.reshape(-1)), ops.to_device(offs), np.full(5 + j, 300, np.int64)))
+    together = pipe3.run_lanes(parts)
+    torch.cuda.synchronize()
+    for (s_, q_, o_, l_), got in zip(parts, together):
+        alone = pipe.run_device_batch(s_, q_, o_, l_)
+        assert torch.equal(alone["logits"], got["logits"]) and torch.equal(alone["smooth"]["smooth"], got["smooth"]["smooth"])
+        assert torch.equal(alone["smooth"]["intervals"], got["smooth"]["intervals"])
+    # fused flow: same file
+    f1, n1, r1 = predict_chop(str(fq), pipe, output_prefix=str(tmp_path / "a"), max_reads=9, max_tokens=20_000)
+    f3, n3, r3 = predict_chop(str(fq), pipe3, output_prefix=str(tmp_path / "b"), max_reads=9, max_tokens=20_000)
+    assert (n1, r1) == (n3, r3) == (70, r1) and open(f1, "rb").read() == open(f3, "rb").read()
