@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct synthetic batches kept in HBM")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DC_LANES", "1")),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DC_LANES", "4")),
                     help="HIP streams (+ model handles) a step's batch is split over: the sub-batches' kernels overlap")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")

@@ -249,6 +249,10 @@ int ensure(DevBuf& b, size_t bytes) {
   // the long-convolution kernel does not write them.  Starting from zeros keeps them finite for good, so they
   // can neither trip the fp16 range guard nor feed NaNs into the LayerNorm statistics of their tile.
   DC_HIP_CHECK(hipMemset(b.p, 0, bytes));
+  // hipMemset runs on the NULL stream, which a non-blocking stream (torch side streams, any caller's own stream) does not
+  // wait for: without this the zero-fill could land in the middle of the first forward that uses the buffer (found by the
+  // lanes test of round 3: the first batch on every side stream came out wrong)
+  DC_HIP_CHECK(hipStreamSynchronize(nullptr));
   b.bytes = bytes;
   return DC_OK;
 }
@@ -828,6 +832,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     if (rc0) return rc0;
     m->d_overflow = (int*)p;
     DC_HIP_CHECK(hipMemset(p, 0, sizeof(int)));
+    DC_HIP_CHECK(hipStreamSynchronize(nullptr));  // NULL-stream memset: complete before any caller stream can touch it
   }
   const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;
   int rc;
