@@ -119,8 +119,9 @@ int64_t hyena_fft15_scratch_bytes(int n_reads, int D);
 int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float* tw, const float* spec,
                        float* scratch);
 int hyena3_units(int kf_taps);  // 16-byte units per (plane, shift) copy of the bf16 filter planes
+int launch_filter_scale(hipStream_t st, const float* kf, int D, int kf_taps, float* ch_scale, float* ch_inv_scale);
 int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
-                         unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale);
+                         unsigned short* kfp_f16, const float* ch_scale);
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                  int64_t Tp, float* x, float* qpad);

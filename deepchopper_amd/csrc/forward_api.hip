@@ -293,7 +293,8 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
     DC_HIP_CHECK(hipMalloc((void**)&L.kf, (size_t)c.d_model * taps * sizeof(float)));
     DC_HIP_CHECK(hipMalloc((void**)&L.kfp, (size_t)c.d_model * 3 * 8 * hyena3_units((int)taps) * 16));
     DC_HIP_CHECK(hipMalloc((void**)&L.kfq, (size_t)c.d_model * 2 * 8 * hyena3_units((int)taps) * 16));
-    if (!L.kscale) {
+    const bool need_scale = !L.kscale;
+    if (need_scale) {
       DC_HIP_CHECK(hipMalloc((void**)&L.kscale, (size_t)c.d_model * sizeof(float)));
       DC_HIP_CHECK(hipMalloc((void**)&L.kinv, (size_t)c.d_model * sizeof(float)));
     }
@@ -312,9 +313,26 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
     f.shift = c.filter_shift;
     f.out = L.kf;
     f.out_stride = taps;
-    int rc = launch_filter(st, f);
-    if (rc) return rc;
-    if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp, L.kfq, L.kscale, L.kinv))) return rc;
+    int rc;
+    if (need_scale) {
+      // the fp16x3 scale of a channel's filter is a property of the whole filter: take it once from all max_seq_len taps
+      // (a temporary full-length materialisation), so that results do not depend on the lengths the handle saw before
+      const int64_t full = (((int64_t)c.max_seq_len + 1023) / 1024) * 1024;
+      float* tmp = nullptr;
+      DC_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)c.d_model * full * sizeof(float)));
+      FilterArgs ff = f;
+      ff.n_taps = (int)full;
+      ff.out = tmp;
+      ff.out_stride = full;
+      if ((rc = launch_filter(st, ff)) || (rc = launch_filter_scale(st, tmp, c.d_model, (int)full, L.kscale, L.kinv))) {
+        (void)hipFree(tmp);
+        return rc;
+      }
+      DC_HIP_CHECK(hipStreamSynchronize(st));
+      DC_HIP_CHECK(hipFree(tmp));
+    }
+    if ((rc = launch_filter(st, f))) return rc;
+    if ((rc = launch_filter_planes(st, L.kf, c.d_model, (int)taps, L.kfp, L.kfq, L.kscale))) return rc;
   }
   m->kf_taps = taps;
   for (bool& v : m->kspec_valid) v = false;
@@ -602,7 +620,12 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   int rc;
   if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
   if ((rc = ensure_workspace(m, m->Tp))) return rc;
-  if ((rc = ensure_filters(m, st, (int64_t)m->max_P * 32))) return rc;
+  // taps: the longest read, and every tap an FFT size class in use transforms (its spectrum is built from min(taps, M)
+  // taps: materialising all M makes it -- and with it the last bits of the result -- independent of what the handle saw before)
+  int64_t taps_needed = (int64_t)m->max_P * 32;
+  for (int b = 0; b < 6; ++b)
+    if (m->fft_count[b]) taps_needed = std::max<int64_t>(taps_needed, (int64_t)1 << (10 + b));
+  if ((rc = ensure_filters(m, st, taps_needed))) return rc;
   for (int b = 0; b < 6; ++b)
     if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
   constexpr int kFft15Batch = 16;  // reads per launch pair of the 2^15 form: 64 MiB of scratch each

@@ -1769,12 +1769,19 @@ __global__ __launch_bounds__(256) void filter_scale_kernel(const float* __restri
   }
 }
 
-int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
-                         unsigned short* kfp_f16, float* ch_scale, float* ch_inv_scale) {
-  const int nu = hyena3_units(kf_taps);
-  const int64_t total = (int64_t)D * 8 * nu;
+// per-channel fp16x3 scale of a layer's filter from `kf_taps` materialised taps (called ONCE per layer, on the filter at
+// its full length: a scale taken from the taps materialised so far would make a read's logits depend -- in the last
+// bits -- on the longest read the handle happened to see before)
+int launch_filter_scale(hipStream_t st, const float* kf, int D, int kf_taps, float* ch_scale, float* ch_inv_scale) {
   hipLaunchKernelGGL(filter_scale_kernel, dim3(D), dim3(256), 0, st, kf, kf_taps, ch_scale, ch_inv_scale);
   DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, unsigned short* kfp_bf16,
+                         unsigned short* kfp_f16, const float* ch_scale) {
+  const int nu = hyena3_units(kf_taps);
+  const int64_t total = (int64_t)D * 8 * nu;
   hipLaunchKernelGGL(filter_planes_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, kf, D, kf_taps,
                      nu, ch_scale, kfp_bf16);
   DC_LAUNCH_CHECK();

@@ -584,6 +584,8 @@ def test_pipeline_lanes_give_identical_results(env, tmp_path):
 
     pipe3 = PredictPipeline(DeepChopper.from_state_dict(sd), lanes=3)
     assert pipe3.lanes == 3 and pipe.lanes == 1
+    # (`pipe` has run other tests' batches, the lane handles are fresh and each sees a third of the chunks: results must not
+    # depend on a handle's history -- the fp16x3 filter scale and the FFT spectra are taken from the full filter)
     seqs, quals, ids = synth.synth_reads_mixed(70, 100, 2500, seed=23)
     fq = tmp_path / "mixed.fq"
     fq.write_bytes(synth.to_fastq(seqs, quals, ids))
