@@ -181,8 +181,6 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=1000)
     ap.add_argument("--resident-batches", type=int, default=2, help="distinct synthetic batches kept in HBM")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DC_LANES", "4")),
-                    help="HIP streams (+ model handles) a step's batch is split over: the sub-batches' kernels overlap")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "fp16x3"], default=os.environ.get("DC_GEMM_MODE", "fp16x3"))
@@ -227,42 +225,31 @@ def main():
     sd = synthetic_state_dict(0)
     model = DeepChopper.from_state_dict(sd)
     model.net.set_gemm_mode(args.gemm_mode)
-    pipe = PredictPipeline(model, lanes=args.lanes)
-    pipe.set_gemm_mode(args.gemm_mode)
+    pipe = PredictPipeline(model)
     B, L = args.batch, args.read_len
-    K = pipe.lanes
-    nets = [ln.net for ln in pipe._lanes]
 
     # rank-local shard of the synthetic read set, resident in HBM before the timed region
     batches = []
     host_first = None
-    # a step's batch of B reads is cut into K contiguous sub-batches (K = lanes; the last one takes the remainder)
-    cuts = [B * j // K for j in range(K + 1)]
     for j in range(args.resident_batches):
         start = (rank * args.resident_batches + j) * B
         seq, qual, ids = synth.synth_reads_fixed(B, L, seed=42, start_index=start)
         if host_first is None:
             host_first = (seq, qual, ids)
-        subs = []
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            offs = np.arange(b - a + 1, dtype=np.int64) * L
-            subs.append((ops.to_device(seq[a:b].reshape(-1)), ops.to_device(qual[a:b].reshape(-1)), ops.to_device(offs),
-                         np.full(b - a, L, np.int64)))
-        batches.append(subs)
+        offs = np.arange(B + 1, dtype=np.int64) * L
+        batches.append((ops.to_device(seq.reshape(-1)), ops.to_device(qual.reshape(-1)), ops.to_device(offs)))
+    lens = np.full(B, L, np.int64)
 
     def step(j):
-        """One pass of the hot path over one batch of B reads; returns the per-lane results (lane order = read order)."""
-        return pipe.run_lanes(batches[j % len(batches)], want_labels=True)
+        s, q, o = batches[j % len(batches)]
+        return pipe.run_device_batch(s, q, o, lens, want_labels=True)
 
     from deepchopper_amd.sharding import dist_barrier as barrier, dist_max
 
     for j in range(args.warmup):
         step(j)
     torch.cuda.synchronize()
-    # Per-kernel HIP events bracket the launches of the timed region only on ONE stream: with K > 1 lanes the kernels of
-    # K batches share the GPU and an event bracket measures shared time, so the per-kernel leg runs separately (below).
-    profile_timed = not args.no_profile and K == 1
-    if profile_timed:
+    if not args.no_profile:
         model.net.set_profiling(True)
         model.net.profile_reset()
     barrier()
@@ -276,34 +263,9 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist_max(elapsed, device="cuda" if backend == "nccl" else "cpu")  # the slowest rank defines the job's time
 
-    fp16_overflow = sum(n.overflow() for n in nets) if args.gemm_mode == "fp16x3" else 0  # range guard of the fp16 split
-    prof = model.net.profile() if profile_timed else {}
+    fp16_overflow = model.net.overflow() if args.gemm_mode == "fp16x3" else 0  # range guard of the fp16 split
+    prof = model.net.profile() if not args.no_profile else {}
     model.net.set_profiling(False)
-    single = None
-    if not args.no_profile and K > 1:
-        # single-stream leg: the same batches, whole, on lane 0, every launch bracketed by HIP events on its stream ->
-        # per-kernel durations that mean one kernel on the whole GPU (what `roofline` and rocprofv3 --stats of
-        # `bench.py --lanes 1` describe)
-        whole = []
-        for subs in batches:
-            whole.append((torch.cat([x[0] for x in subs]), torch.cat([x[1] for x in subs]),
-                          ops.to_device(np.arange(B + 1, dtype=np.int64) * L), np.full(B, L, np.int64)))
-        pipe.run_device_batch(*whole[0], want_labels=True)
-        torch.cuda.synchronize()
-        model.net.set_profiling(True)
-        model.net.profile_reset()
-        barrier()
-        t1 = time.perf_counter()
-        for j in range(args.steps):
-            pipe.run_device_batch(*whole[j % len(whole)], want_labels=True)
-        torch.cuda.synchronize()
-        barrier()
-        dt1 = dist_max(time.perf_counter() - t1, device="cuda" if backend == "nccl" else "cpu")
-        prof = model.net.profile()
-        model.net.set_profiling(False)
-        single = {"value": round(world * B * args.steps / dt1, 2), "ms_per_step": round(dt1 / args.steps * 1e3, 3), "steps": args.steps,
-                  "what": "the same step on ONE HIP stream (lanes = 1), per-kernel HIP events on: source of `stages` and `roofline`"}
-        del whole
     per_rank_s = [elapsed]
     if world > 1:
         own = time.perf_counter() - t0  # not comparable across ranks to better than the barrier; informational
@@ -315,7 +277,7 @@ def main():
     # driver's record also carries the throughput of the mode that needs no range guard
     strict = None
     if args.strict_steps > 0 and args.gemm_mode != "bf16x6":
-        pipe.set_gemm_mode("bf16x6")
+        model.net.set_gemm_mode("bf16x6")
         step(0)
         torch.cuda.synchronize()
         barrier()
@@ -327,7 +289,7 @@ def main():
         dt = dist_max(time.perf_counter() - t1, device="cuda" if backend == "nccl" else "cpu")
         strict = {"value": round(world * B * args.strict_steps / dt, 2), "steps": args.strict_steps,
                   "ms_per_step": round(dt / args.strict_steps * 1e3, 3)}
-        pipe.set_gemm_mode(args.gemm_mode)
+        model.net.set_gemm_mode(args.gemm_mode)
 
     if rank == 0:
         tokens_per_launch = B * (L + 1)
@@ -355,11 +317,7 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_ms": stages[dom]["avg_ms"], "launches_per_step": stages[dom]["launches"] // max(args.steps, 1),
                     "share_of_forward": stages[dom]["share"],
-                    "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[dom] * tokens_per_launch,
-                    "measured_on": ("the timed region (one HIP stream, HIP events on it)" if K == 1 else
-                                    f"the single-stream leg of this run ({args.steps} steps, `single_stream`): in the timed region the kernels of "
-                                    f"{K} lanes share the GPU, so an event bracket there measures shared time, not this kernel's"),
-                    "whole_step_tflops_timed_region": round(FLOPS_PER_TOKEN_TOTAL * tokens_per_launch * args.steps / elapsed / 1e12, 2)}
+                    "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[dom] * tokens_per_launch}
             if "traffic_bpt" in mode:
                 padded = -(-(B * (-(-(L + 1) // 32) * 32)) // 256) * 256  # reads start at multiples of 32 token slots
                 roof["traffic"] = int(mode["traffic_bpt"] * padded)
@@ -390,27 +348,21 @@ def main():
                    "reference_prose_cpu_reads_per_s": [46, 139],  # docs/faq.md:78-80 (2-6 h per 1 M reads), context only
                    "note": "CPU restatement (oracle/), not the reference binary: its backbone cannot be loaded here (SURVEY 8c)"}
             # per-base F1 of the GPU labels against the oracle's on the sampled reads (expected 1.0)
-            lanes_res = step(0)  # per-lane results, lane order = read order
+            res = step(0)
             torch.cuda.synchronize()
+            o = res["smooth"]["offsets"].cpu().numpy()
+            pred = res["smooth"]["pred"].cpu().numpy()
             tp = fp = fn = 0
             same_iv = True
-            r0 = 0
-            for res in lanes_res:
-                o = res["smooth"]["offsets"].cpu().numpy()
-                pred = res["smooth"]["pred"].cpu().numpy()
-                iv = res["smooth"]["intervals"].cpu().numpy()
-                niv = res["smooth"]["n_intervals"].cpu().numpy()
-                for k in range(len(niv)):
-                    r = r0 + k
-                    if r >= n_done:
-                        break
-                    g = pred[o[k]: o[k + 1]]
-                    e, _, eiv = ref[ids[r]]
-                    tp += int(np.sum((g == 1) & (e == 1)))
-                    fp += int(np.sum((g == 1) & (e == 0)))
-                    fn += int(np.sum((g == 0) & (e == 1)))
-                    same_iv &= [tuple(x) for x in iv[k, : niv[k]].tolist()] == eiv
-                r0 += len(niv)
+            iv = res["smooth"]["intervals"].cpu().numpy()
+            niv = res["smooth"]["n_intervals"].cpu().numpy()
+            for r in range(n_done):
+                g = pred[o[r]: o[r + 1]]
+                e, _, eiv = ref[ids[r]]
+                tp += int(np.sum((g == 1) & (e == 1)))
+                fp += int(np.sum((g == 1) & (e == 0)))
+                fn += int(np.sum((g == 0) & (e == 1)))
+                same_iv &= [tuple(x) for x in iv[r, : niv[r]].tolist()] == eiv
             f1 = {"per_base_f1_vs_oracle": round(2 * tp / max(2 * tp + fp + fn, 1), 6), "reads": n_done,
                   "intervals_identical": bool(same_iv)}
 
@@ -435,12 +387,9 @@ def main():
             "config": {"workload": f"configs[1]: synthetic {L}-bp reads, {world}xMI355X, batches of {B} reads per GPU "
                                    f"(tokenise -> HyenaDNA forward -> argmax/smooth/intervals), synthetic weights",
                        "reads_per_step_per_gpu": B, "read_len": L, "tokens_per_read": L + 1,
-                       "lanes": K, "lanes_note": (f"a step's {B} reads run as {K} sub-batches on {K} HIP streams (one model handle = "
-                                                  f"one workspace each), whose kernels overlap" if K > 1 else "one HIP stream"),
                        "parallelism": f"read-sharded x{world}, no collectives",
                        "control_plane": (backend if world > 1 else "none") + " (barrier + max of one host scalar)"},
             "roofline": roof,
-            "single_stream": single,
             "value_bf16x6": strict["value"] if strict else None,
             "bf16x6_leg": strict,
             "file_e2e": e2e,

@@ -217,7 +217,7 @@ def _predict(args, argv: list[str]) -> int:
     torch.cuda.set_device(local_rank)
     model_name = HUB_NAMES.get(args.model.lower(), args.model)
     model = DeepChopper.from_pretrained(model_name)
-    pipe = PredictPipeline(model, smooth=_smooth_params(args), lanes=args.lanes)
+    pipe = PredictPipeline(model, smooth=_smooth_params(args))
     out_dir = Path(args.output or "predictions")
     max_reads, max_bases = _chunk_limits(args, world)
     pipe_src = None
@@ -328,8 +328,6 @@ def main(argv=None) -> int:
     p.add_argument("--max-tokens", type=int, default=2_000_000, help="token budget per --native / --chop batch")
     p.add_argument("--no-pt", action="store_true", help="skip the 28 B/token .pt wire format (use with --native: "
                    "labels / intervals only)")
-    p.add_argument("--lanes", type=int, default=int(os.environ.get("DC_LANES", "4")),
-                   help="batches in flight on separate HIP streams (one model workspace each): their kernels overlap; 1 = one stream")
     p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native / --chop batch (-b applies to reference batches)")
     p.add_argument("--chop", action="store_true", help="fused predict -> chop: write the chopped reads as BGZF FASTQ, no .pt files")
     p.add_argument("--chop-output", default=None, help="output prefix of --chop (default: the FASTQ's stem, as deepchopper chop)")

@@ -22,15 +22,7 @@ class TokenClassificationModel:
 
     def __init__(self, state_dict, cfg: HyenaDNAConfig | None = None):
         self.cfg = cfg or HyenaDNAConfig()
-        self._state_dict = state_dict  # kept for clone_net(): extra lanes of the pipeline own a handle (workspace) each
         self.net = ops.HipModel(state_dict, self.cfg)
-
-    def clone_net(self) -> "ops.HipModel":
-        """Another `dc_model` handle over the same weights (own workspace, own filters): batches on different HIP
-        streams need one each (`PredictPipeline(lanes=N)`)."""
-        net = ops.HipModel(self._state_dict, self.cfg)
-        net.set_gemm_mode(self.net.gemm_mode)
-        return net
 
     def forward(self, input_ids: torch.Tensor, input_quals: torch.Tensor) -> torch.Tensor:
         """`TokenClassificationLit.forward` (basic_module.py:90-100).  SYNCHRONISES the stream in the default fp16x3

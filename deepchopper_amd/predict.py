@@ -62,64 +62,14 @@ class _Slot:
         self.n = 0
 
 
-class _Lane:
-    """One HIP stream + one model handle (workspace).  Lane 0 is the caller's current stream and the model's own handle."""
-
-    def __init__(self, net, stream):
-        self.net, self.stream = net, stream
-
-    def context(self):
-        import contextlib
-
-        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
-
-
 class PredictPipeline:
-    """tokenise -> forward -> smooth on device-resident batches.
+    """tokenise -> forward -> smooth on device-resident batches."""
 
-    lanes > 1: consecutive batches are launched on different HIP streams (one model handle = one workspace each), so
-    that the kernels of independent batches overlap.  A step is a strict chain of kernels that are either matrix-pipe
-    bound and power limited (fused MLP, head: ~75 % of the time) or HBM bound (out_proj, long convolution), each with a
-    partial last wave of workgroups; on one stream none of that overlaps.  Measured on 1 kb reads: +7 % with three
-    lanes (profiles/r03_lanes_sweep.json).  Results are identical: the lanes run the same kernels on disjoint data."""
-
-    def __init__(self, model, max_length: int = DEFAULT_MAX_LENGTH, smooth: SmoothParams | None = None, lanes: int = 1):
+    def __init__(self, model, max_length: int = DEFAULT_MAX_LENGTH, smooth: SmoothParams | None = None):
         self.model = model
         self.max_length = max_length
         self.smooth = smooth or SmoothParams()
         self._copy_stream = None
-        self._lanes = [_Lane(model.net, None)]
-        for _ in range(1, max(1, int(lanes))):
-            self._lanes.append(_Lane(model.clone_net(), torch.cuda.Stream()))
-
-    @property
-    def lanes(self) -> int:
-        return len(self._lanes)
-
-    def set_gemm_mode(self, mode: str) -> None:
-        for ln in self._lanes:
-            ln.net.set_gemm_mode(mode)
-
-    def run_lanes(self, batches, **kw):
-        """One device batch per lane, launched back to back on the lanes' streams (all asynchronous).  `batches`:
-        (seq, qual, offsets, lens_host) tuples, at most one per lane; returns their results in order.  The side streams
-        first wait for the caller's stream (inputs may have been produced there) and the caller's stream waits for
-        them at the end, so that stream-ordered consumers downstream stay correct."""
-        assert len(batches) <= len(self._lanes)
-        cur = torch.cuda.current_stream()
-        start = torch.cuda.Event()
-        start.record(cur)
-        out = []
-        for ln, (s, q, o, lens) in zip(self._lanes, batches):
-            with ln.context():
-                if ln.stream is not None:
-                    ln.stream.wait_event(start)
-                out.append(self.run_device_batch(s, q, o, lens, net=ln.net, **kw))
-                if ln.stream is not None:
-                    done = torch.cuda.Event()
-                    done.record(ln.stream)
-                    cur.wait_event(done)
-        return out
 
     # ---- stage 1 ---------------------------------------------------------------------
     def tokenize(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, max_len_bases: int,
@@ -131,7 +81,7 @@ class PredictPipeline:
     # ---- whole hot path on one device batch ---------------------------------------------
     def run_device_batch(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, lens_host: np.ndarray,
                          *, reference_padding: bool = False, want_labels: bool = True, ids_i64: bool = False,
-                         staging: _Pinned | None = None, net=None):
+                         staging: _Pinned | None = None):
         """seq/qual: concatenated raw bytes on the device; offsets int64[n+1] on the device;
         lens_host: read lengths (host copy, known from parsing).
 
@@ -163,11 +113,10 @@ class PredictPipeline:
 
         tok = self.tokenize(seq, qual, offsets, max_len, pad_left=True, ids_i64=ids_i64, want_labels=want_labels)
         assert tok["input_ids"].shape[1] == row_stride
-        net = net or self.model.net
         if reference_padding or bool(np.all(ntok == row_stride)):
-            logits = net.forward(tok["input_ids"], tok["input_quals"])
+            logits = self.model.net.forward(tok["input_ids"], tok["input_quals"])
         else:
-            logits = net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
+            logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
         sp = self.smooth
         sm = ops.smooth_intervals_from_logits(logits, d_first, d_len, window=sp.window, min_interval=sp.min_interval,
                                               approved=sp.approved, want_labels=want_labels,
@@ -258,18 +207,13 @@ class PredictPipeline:
 
         borrow=True: the yielded host arrays are views into pinned staging that is reused once the consumer
         asks for the next result (the fused chop driver consumes them at once); otherwise they are copies."""
+        net = self.model.net
         dev = torch.device("cuda", torch.cuda.current_device())
+        compute = torch.cuda.current_stream()
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream()
         copy_stream = self._copy_stream
-        depth = len(self._lanes)  # batches in flight: one per lane
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
-        for ln in self._lanes:
-            if ln.stream is not None:
-                ln.stream.wait_event(ready)
-        n_launched = 0
-        n_slots = max(1, prefetch) + 2 + depth
+        n_slots = max(1, prefetch) + 3
         free: queue.Queue = queue.Queue()
         for _ in range(n_slots):
             free.put(_Slot())
@@ -313,13 +257,6 @@ class PredictPipeline:
                 q.put(e)
 
         def launch(slot: _Slot):
-            nonlocal n_launched
-            lane = self._lanes[n_launched % depth]
-            n_launched += 1
-            with lane.context():
-                return launch_on(slot, lane.net, torch.cuda.current_stream())
-
-        def launch_on(slot: _Slot, net, compute):
             n, nb = slot.n, int(slot.offs[slot.n])
             d_seq = torch.empty(nb, dtype=torch.uint8, device=dev)
             d_qual = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -333,7 +270,7 @@ class PredictPipeline:
                 net.set_overflow_target(counter)
             try:
                 res = self.run_device_batch(d_seq, d_qual, d_offs, slot.lens, reference_padding=reference_padding,
-                                            want_labels=want_labels, ids_i64=ids_i64, staging=slot.pin, net=net)
+                                            want_labels=want_labels, ids_i64=ids_i64, staging=slot.pin)
             finally:
                 if guard:
                     net.set_overflow_target(None)
@@ -388,23 +325,19 @@ class PredictPipeline:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        import collections
-
-        pending: collections.deque = collections.deque()
+        pending = None
         try:
             while True:
                 item = q.get()
                 if isinstance(item, BaseException):
                     raise item
-                if item is not None:
-                    launched = launch(item)
-                    if serialize:
-                        launched["copied"].synchronize()
-                    pending.append(launched)
-                while pending and (item is None or len(pending) > depth):
-                    b = pending.popleft()
-                    yield collect(b)
-                    free.put(b["slot"])  # the consumer is done with the borrowed views
+                launched = launch(item) if item is not None else None
+                if serialize and launched is not None:
+                    launched["copied"].synchronize()
+                if pending is not None:
+                    yield collect(pending)
+                    free.put(pending["slot"])  # the consumer is done with the borrowed views
+                pending = launched
                 if item is None:
                     break
         finally:

@@ -570,57 +570,47 @@ def test_multi_rank_chop_output_is_in_input_order_and_byte_identical_to_one_gpu(
     assert left == [], left
 
 
-def test_pipeline_lanes_give_identical_results(env, tmp_path):
-    """`PredictPipeline(lanes=3)`: consecutive batches run on three HIP streams with a model handle (workspace) each.
-    Same kernels on disjoint data: every chunk's labels, smoothed labels, intervals, kept segments AND logits equal the
-    one-lane pipeline's bit for bit, in input order; `run_lanes` equals `run_device_batch` on the pieces; the fused
-    predict -> chop output is the same file."""
+def test_results_do_not_depend_on_a_handles_history_or_stream(env, tmp_path):
+    """Two properties the round-3 "lanes" experiment (several model handles on several HIP streams) exposed:
+    (1) a read's logits must not depend on what its handle processed before -- the fp16x3 scale of a channel's long filter
+        is taken from the full-length filter and the FFT spectra from all taps of their size class, not from the taps
+        materialised so far;
+    (2) a handle driven from a NON-BLOCKING side stream must give the same result as on the default stream -- the
+        workspace zero-fill used to run on the NULL stream, which such a stream does not wait for: the first forward raced
+        with it (and the cached index arrays could stay zero for good, which made side streams look 20 % "faster")."""
     torch, sd, pipe = env
     from deepchopper_amd import ops, synth
-    from deepchopper_amd.chop import predict_chop
-    from deepchopper_amd.fastq import FastqReader
     from deepchopper_amd.model import DeepChopper
     from deepchopper_amd.predict import PredictPipeline
 
-    pipe3 = PredictPipeline(DeepChopper.from_state_dict(sd), lanes=3)
-    assert pipe3.lanes == 3 and pipe.lanes == 1
-    # (`pipe` has run other tests' batches, the lane handles are fresh and each sees a third of the chunks: results must not
-    # depend on a handle's history -- the fp16x3 filter scale and the FFT spectra are taken from the full filter)
-    seqs, quals, ids = synth.synth_reads_mixed(70, 100, 2500, seed=23)
-    fq = tmp_path / "mixed.fq"
-    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    def batch(n, lo, hi, seed):
+        seqs, quals, _ = synth.synth_reads_mixed(n, lo, hi, seed=seed)
+        sb, offs = ops.pack_reads(seqs)
+        qb, _ = ops.pack_reads(quals)
+        return ops.to_device(sb), ops.to_device(qb), ops.to_device(offs), np.diff(offs)
 
-    def stream(p):
-        out = []
-        with FastqReader(str(fq)) as rd:
-            for res in p.predict_stream(rd.chunks(max_reads=9, cap_bases=20_000)):
-                lg = res["device"]["logits"].cpu().numpy()
-                stride = lg.shape[1]
-                # the dense logits tensor is only written where a read has tokens (rows are left-aligned to the longest read)
-                valid = [lg[r, stride - int(n) - 1:] for r, n in enumerate(res["pred_len"])]
-                out.append({k: np.array(res[k], copy=True) for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep", "offsets")}
-                           | {"names": list(res["names"]), "logits": np.concatenate(valid)})
-        return out
+    short, long_ = batch(9, 100, 900, 1), batch(3, 2600, 5000, 2)   # the long batch takes the FFT path and more filter taps
 
-    one, three = stream(pipe), stream(pipe3)
-    assert len(one) == len(three) >= 7 and [n for c in three for n in c["names"]] == ids
-    for a, b in zip(one, three):
-        assert a["names"] == b["names"]
-        for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep", "offsets", "logits"):
-            assert np.array_equal(a[k], b[k]), k
-    # run_lanes: three device batches at once == each of them alone
-    parts = []
-    for j in range(3):
-        sq, ql, _ = synth.synth_reads_fixed(5 + j, 300, seed=30 + j)
-        offs = np.arange(5 + j + 1, dtype=np.int64) * 300
-        parts.append((ops.to_device(sq.reshape(-1)), ops.to_device(ql.reshape(-1)), ops.to_device(offs), np.full(5 + j, 300, np.int64)))
-    together = pipe3.run_lanes(parts)
-    torch.cuda.synchronize()
-    for (s_, q_, o_, l_), got in zip(parts, together):
-        alone = pipe.run_device_batch(s_, q_, o_, l_)
-        assert torch.equal(alone["logits"], got["logits"]) and torch.equal(alone["smooth"]["smooth"], got["smooth"]["smooth"])
-        assert torch.equal(alone["smooth"]["intervals"], got["smooth"]["intervals"])
-    # fused flow: same file
-    f1, n1, r1 = predict_chop(str(fq), pipe, output_prefix=str(tmp_path / "a"), max_reads=9, max_tokens=20_000)
-    f3, n3, r3 = predict_chop(str(fq), pipe3, output_prefix=str(tmp_path / "b"), max_reads=9, max_tokens=20_000)
-    assert (n1, r1) == (n3, r3) == (70, r1) and open(f1, "rb").read() == open(f3, "rb").read()
+    def valid_logits(res, lens):
+        lg = res["logits"].cpu().numpy()
+        return np.concatenate([lg[r, lg.shape[1] - int(n) - 1:] for r, n in enumerate(lens)])
+
+    fresh = PredictPipeline(DeepChopper.from_state_dict(sd))
+    a = valid_logits(fresh.run_device_batch(*short), short[3])           # short reads on a handle that has seen nothing
+    seasoned = PredictPipeline(DeepChopper.from_state_dict(sd))
+    seasoned.run_device_batch(*long_)                                     # ... and after long reads grew filters / spectra
+    b = valid_logits(seasoned.run_device_batch(*short), short[3])
+    assert np.array_equal(a, b)
+    c = valid_logits(pipe.run_device_batch(*short), short[3])             # the module's handle: many other tests before
+    assert np.array_equal(a, c)
+    side = torch.cuda.Stream()                                            # non-blocking, as torch creates them
+    other = PredictPipeline(DeepChopper.from_state_dict(sd))
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        r1 = other.run_device_batch(*short)                              # FIRST forward of this handle, on the side stream
+        r2 = other.run_device_batch(*long_)
+    side.synchronize()
+    assert np.array_equal(valid_logits(r1, short[3]), a)
+    assert np.array_equal(valid_logits(r2, long_[3]), valid_logits(seasoned.run_device_batch(*long_), long_[3]))
+    for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep"):
+        assert torch.equal(r1["smooth"][k], fresh.run_device_batch(*short)["smooth"][k]), k
