@@ -292,7 +292,7 @@ def _predict(args, argv: list[str]) -> int:
     return 0
 
 
-def _add_chop_options(p, prefix_output: bool) -> None:
+def _add_chop_options(p, prefix_output: bool, threads: int = 2) -> None:
     p.add_argument("--smooth-window", type=int, default=21)
     p.add_argument("--min-interval-size", type=int, default=13)
     p.add_argument("--approved-intervals", type=int, default=20)
@@ -302,7 +302,10 @@ def _add_chop_options(p, prefix_output: bool) -> None:
     p.add_argument("--output-chopped", "--ocq", dest="ocq", action="store_true",
                    help="output the chopped (adapter) segments only (deepchopper/cli.py:163 `--output-chopped`; "
                         "`--ocq` is the chop binary's spelling, src/bin/predict.rs:60-62)")
-    p.add_argument("--threads", "-t", type=int, default=2, help="BGZF compression workers for the output (smoothing itself runs on the GPU)")
+    p.add_argument("--threads", "-t", type=int, default=threads,
+                   help="BGZF compression workers for the output (smoothing itself runs on the GPU).  `chop`: 2 as the reference "
+                        "(cli.py:165); `predict --chop`: 4 -- one GPU emits ~30 Mbases/s of FASTQ text, which costs 2.4 cores of "
+                        "zlib level 6 (profiles/r03_host_budget_8rank.json: 21.4 k reads/s with 2 workers, 25.7 k with 4)")
     if prefix_output:
         p.add_argument("--output", "-o", default=None, help="Output prefix")
 
@@ -331,7 +334,7 @@ def main(argv=None) -> int:
     p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native / --chop batch (-b applies to reference batches)")
     p.add_argument("--chop", action="store_true", help="fused predict -> chop: write the chopped reads as BGZF FASTQ, no .pt files")
     p.add_argument("--chop-output", default=None, help="output prefix of --chop (default: the FASTQ's stem, as deepchopper chop)")
-    _add_chop_options(p, prefix_output=False)
+    _add_chop_options(p, prefix_output=False, threads=4)
     p.add_argument("--report-json", default=None, help=argparse.SUPPRESS)          # host-budget accounting of the run
     p.add_argument("--chunk-fd", type=int, default=None, help=argparse.SUPPRESS)   # worker: chunks come from the parent
     p.add_argument("--part-path", default=None, help=argparse.SUPPRESS)            # worker: per-rank BGZF part

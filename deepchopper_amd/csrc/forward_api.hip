@@ -452,23 +452,29 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   key.insert(key.end(), h_ntok, h_ntok + n_reads);
   if (key == m->h_geom && m->Tp > 0) return DC_OK;
 
+  // Packed layout: a read starts at a multiple of 4 token slots (16-byte aligned fp32 rows for the float4 / 8-byte
+  // accesses of the long-convolution kernels) and owns ceil4(ntok) slots.  (Rounds 1-2 gave every read whole 32-token
+  // blocks: 1 001 tokens took 1 024 slots, 2.2 % of every GEMM's work; 513 tokens 544, 6 %.)  The long-convolution
+  // kernels still walk a read in 32-token blocks: the tail of its last block overlaps the next read's slots, which they
+  // may READ (causal: a later position never reaches an earlier output) but must not write -- their stores are masked
+  // by the read's slot count.  32 slots of slack behind the last read keep those reads inside the buffers.
   std::vector<int32_t> nblk(n_reads), toff(n_reads);
-  int64_t blocks = 0;
+  int64_t slots = 0;
   int maxP = 0, minP = 1 << 30;
   for (int r = 0; r < n_reads; ++r) {
     DC_REQUIRE(h_ntok[r] >= 1, "every read needs at least one token");
     DC_REQUIRE(h_first[r] >= 0 && (int64_t)h_first[r] + h_ntok[r] <= row_stride, "read exceeds its row");
     nblk[r] = (h_ntok[r] + 31) / 32;
-    DC_REQUIRE(blocks * 32 < (int64_t)1 << 31, "batch too large for 32-bit token offsets");
-    toff[r] = (int32_t)(blocks * 32);
-    blocks += nblk[r];
+    DC_REQUIRE(slots < ((int64_t)1 << 31) - 64, "batch too large for 32-bit token offsets");
+    toff[r] = (int32_t)slots;
+    slots += ((int64_t)h_ntok[r] + 3) & ~(int64_t)3;
     maxP = std::max(maxP, nblk[r]);
     minP = std::min(minP, nblk[r]);
   }
-  const int64_t Tp = ((blocks * 32 + 255) / 256) * 256;  // multiple of every GEMM token tile
+  const int64_t Tp = ((slots + 32 + 255) / 256) * 256;  // + slack, then a multiple of every GEMM token tile
   DC_REQUIRE(Tp < ((int64_t)1 << 31), "batch too large (token count must fit int32)");
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
-  const int64_t n_tb = Tp / 32;
+  const int64_t n_tb = Tp / 4;  // entries of the slot -> read map (one per 4 slots)
 
   // Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by transform size: up to 2^14
   // tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form; the others form groups
@@ -502,10 +508,11 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
   }
-  std::vector<int32_t> blk_read(n_tb, -1);
+  std::vector<int32_t> blk_read(n_tb, -1);  // read that owns slots [4 i, 4 i + 4), -1 = none
   std::vector<int64_t> src_base(n_reads);
   for (int r = 0; r < n_reads; ++r) {
-    for (int b = 0; b < nblk[r]; ++b) blk_read[toff[r] / 32 + b] = r;
+    const int64_t q0 = toff[r] / 4, q1 = q0 + (h_ntok[r] + 3) / 4;
+    std::fill(blk_read.begin() + q0, blk_read.begin() + q1, r);
     src_base[r] = (int64_t)r * row_stride + h_first[r];
   }
 

@@ -1,8 +1,9 @@
 // Forward kernels (F1-F3) for gfx950.
 //
 // Data layout: every activation is CHANNEL-MAJOR, X[C][Tp] fp32, where the token axis Tp is the
-// concatenation of all reads of the batch, each read starting at a multiple of 32 tokens
-// ("packed varlen").  With tokens on the fast axis
+// concatenation of all reads of the batch, each read starting at a multiple of 4 token slots and owning
+// ceil4(tokens) of them ("packed varlen"; the long-convolution kernels walk a read in 32-token blocks and mask
+// their stores at the read's last slot).  With tokens on the fast axis
 //   * a GEMM  C[n][t] = sum_k Wt[k][n] X[k][t]  puts the output channel on the MFMA row (A operand =
 //     pre-transposed weights) and the token on the MFMA column (B operand), so both operands are
 //     k-major, LDS fragment reads are conflict-free ds_read_b32 with unit lane stride, and the
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
-  const int r = blk_read[t >> 5];
+  const int r = blk_read[t >> 2];
   int id = -1;
   float qv = 0.f;
   if (r >= 0) {
@@ -1395,7 +1396,7 @@ __global__ __launch_bounds__(256) void load_hidden_kernel(const float* __restric
                                                           float* __restrict__ x, float* __restrict__ qpad) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
-  const int r = blk_read[t >> 5];
+  const int r = blk_read[t >> 2];
   int64_t s = -1;
   if (r >= 0) {
     const int l = (int)(t - toff[r]);
@@ -1654,6 +1655,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   if (!valid) r = a.grp_reads[g * 32];
   const int64_t off = a.toff[r];
   const int my_nblk = valid ? a.nblk[r] : 0;
+  const int my_nt4 = valid ? (a.ntok[r] + 3) & ~3 : 0;  // slots the read owns (stores beyond belong to the next read)
   const float* ux0 = a.u + (int64_t)c * a.Tp + off;
   float* yrow = a.y + (int64_t)c * a.Tp + off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
@@ -1676,7 +1678,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
         o.y = acc[m][4 * gq + 1] * g1;
         o.z = acc[m][4 * gq + 2] * g2;
         o.w = acc[m][4 * gq + 3] * g3;
-        *reinterpret_cast<float4*>(yrow + t) = o;
+        if (t < my_nt4) *reinterpret_cast<float4*>(yrow + t) = o;
       }
     }
   }
@@ -2058,6 +2060,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   if (!e_valid) re = a.grp_reads[g * 32];
   const int64_t e_off = a.toff[re];
   const int e_nblk = e_valid ? a.nblk[re] : 0;
+  const int e_nt4 = e_valid ? (a.ntok[re] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
   const float* ux0 = a.u + (int64_t)c * a.Tp + e_off;
   float* yrow = a.y + (int64_t)c * a.Tp + e_off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
@@ -2118,7 +2121,8 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<float4*>(yrow + t0 + 4 * j) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+          if (t0 + 4 * j < e_nt4)
+            *reinterpret_cast<float4*>(yrow + t0 + 4 * j) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
       }
     }
   }
@@ -2178,7 +2182,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
-  const int r = blk_read[t >> 5];
+  const int r = blk_read[t >> 2];
   if (r < 0) return;
   const int l = (int)(t - toff[r]);
   if (l >= ntok[r]) return;
@@ -2204,7 +2208,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
                                                           float* __restrict__ logits) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
-  const int r = blk_read[t >> 5];
+  const int r = blk_read[t >> 2];
   if (r < 0) return;
   const int l = (int)(t - toff[r]);
   if (l >= ntok[r]) return;
@@ -2247,7 +2251,7 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
-  const int r = blk_read[t >> 5];
+  const int r = blk_read[t >> 2];
   int id = -1;
   float qv = 0.f;
   if (r >= 0) {
