@@ -319,7 +319,7 @@ def main():
                     "share_of_forward": stages[dom]["share"],
                     "algorithmic_flops_per_launch": FLOPS_PER_TOKEN[dom] * tokens_per_launch}
             if "traffic_bpt" in mode:
-                padded = -(-(B * (-(-(L + 1) // 32) * 32)) // 256) * 256  # reads start at multiples of 32 token slots
+                padded = -(-(B * (-(-(L + 1) // 4) * 4) + 32) // 256) * 256  # a read owns ceil4(tokens) slots; 32 slots of slack; 256-token tiles
                 roof["traffic"] = int(mode["traffic_bpt"] * padded)
                 roof["traffic_kind"] = "constant from the committed PMC profile (bytes per padded token x this launch's tokens), not measured in this run"
                 roof["traffic_source"] = mode["source"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
