@@ -63,6 +63,46 @@ def test_tokenize_batch_matches_oracle(env, ids_i64):
     assert np.all(out["status"].cpu().numpy() == 0)
 
 
+@pytest.mark.parametrize("lens,stride_extra", [
+    ([1, 2, 15, 16, 17, 31, 33, 1], 0),        # every read shorter than two 16-byte chunks; first / last windows leave the buffer
+    ([1000, 7, 1023, 1], 0),                    # row of 1 024 columns: the one-step form at its limit
+    ([1024, 1, 999], 0),                        # 1 025 columns: first two-pass row
+    ([2500, 16, 3000, 48], 0),                  # several steps per wave
+    ([40, 700, 3], 37),                         # rows wider than the longest read (extra left pad)
+])
+@pytest.mark.parametrize("pad_left", [True, False])
+def test_tokenize_chunk_edges(env, lens, stride_extra, pad_left):
+    """The round-3 tokenizer moves 16 bases per lane: reads shorter than a chunk, windows that would leave the packed
+    buffers (first / last read), rows that end inside a chunk, the one-step (<= 1 024 columns) and the two-pass form,
+    left and right padding -- all bit-exact against the oracle's per-read features."""
+    torch, ops = env
+    rng = np.random.default_rng(sum(lens) + stride_extra)
+    al = np.frombuffer(b"ACGTNacgtnU-X ", dtype=np.uint8)
+    seqs = [al[rng.integers(0, len(al) - 1, n)].tobytes() for n in lens]  # (no blanks: they raise a status flag)
+    quals = [rng.integers(34, 74, n).astype(np.uint8).tobytes() for n in lens]
+    ids = [f"e{i}" for i in range(len(lens))]
+    _, feats = _oracle_batch(seqs, quals, ids, 32769)
+    sb, offs = ops.pack_reads(seqs)
+    qb, _ = ops.pack_reads(quals)
+    stride = max(lens) + 1 + stride_extra
+    for ids_i64 in (False, True):
+        out = ops.tokenize_batch(ops.to_device(sb), ops.to_device(qb), ops.to_device(offs), max_length=32769,
+                                 row_stride=stride, pad_left=pad_left, ids_i64=ids_i64)
+        got_ids = out["input_ids"].cpu().numpy().astype(np.int64)
+        got_q = out["input_quals"].cpu().numpy()
+        got_l = out["labels"].cpu().numpy()
+        assert np.all(out["status"].cpu().numpy() == 0)
+        for r, f in enumerate(feats):
+            n = len(f["input_ids"])
+            a = stride - n if pad_left else 0
+            assert np.array_equal(got_ids[r, a: a + n], f["input_ids"]), (r, ids_i64)
+            assert np.array_equal(got_q[r, a: a + n].view(np.uint32), np.asarray(f["input_quals"], np.float32).view(np.uint32))
+            assert np.array_equal(got_l[r, a: a + n], np.asarray(f["labels"], np.int8))
+            rest = np.ones(stride, bool)
+            rest[a: a + n] = False
+            assert np.all(got_ids[r, rest] == 4) and np.all(got_q[r, rest] == 0) and np.all(got_l[r, rest] == -100)
+
+
 def test_tokenize_truncation_and_flags(env):
     torch, ops = env
     from deepchopper_amd import _lib
@@ -290,6 +330,41 @@ def test_smooth_from_logits_reference_fixtures(env, golden_dir, name):
         assert np.array_equal(sm[offs[b]: offs[b + 1]], p.smooth_label(21))
         e_iv = p.smooth_and_select_intervals(21, 13, 20)
         assert niv[b] == len(e_iv) and [tuple(x) for x in iv[b, : niv[b]].tolist()] == e_iv
+
+
+@pytest.mark.parametrize("stride", [1001, 2048, 2049, 4096, 4097])
+@pytest.mark.parametrize("window", [1, 3, 21, 31, 33, 101])
+def test_smooth_from_logits_forms_and_windows(env, stride, window):
+    """Every form of the logits-mode smoothing kernel (64 threads / 2 048 positions, 128 / 4 096, 256 / 65 536, chosen by
+    row stride) with both window evaluations (32-bit register windows up to 31, word-prefix counts above), reads whose
+    lengths sit on the chunk (16), word (64) and form boundaries, first columns > 0, exact ties in the logits."""
+    torch, ops = env
+    from oracle import dc_oracle as o
+
+    rng = np.random.default_rng(stride * 131 + window)
+    lens = [x for x in (1, 15, 16, 17, 63, 64, 65, 150, 999, 1000, 1024, 2047, 2048, 4095, 4096, stride - 1, stride) if x <= stride]
+    B = len(lens)
+    logits = rng.standard_normal((B, stride, 2)).astype(np.float32)
+    logits[:, ::7, 1] = logits[:, ::7, 0]  # exact ties -> label 0
+    for b in range(B):  # runs long enough to survive the length filter
+        for s0 in range(30, lens[b] - 40, 211):
+            logits[b, stride - lens[b] + s0: stride - lens[b] + s0 + 35, 1] = logits[b, stride - lens[b] + s0: stride - lens[b] + s0 + 35, 0] + 1.0
+    first = np.array([stride - n for n in lens], np.int32)
+    length = np.array(lens, np.int32)
+    out = ops.smooth_intervals_from_logits(ops.to_device(logits), ops.to_device(first), ops.to_device(length), window=window,
+                                           min_interval=13, approved=20)
+    offs = out["offsets"].cpu().numpy()
+    pred, sm = out["pred"].cpu().numpy(), out["smooth"].cpu().numpy()
+    niv, iv = out["n_intervals"].cpu().numpy(), out["intervals"].cpu().numpy()
+    nk, kp = out["n_keep"].cpu().numpy(), out["keep"].cpu().numpy()
+    for b, n in enumerate(lens):
+        lg = logits[b, stride - n:]
+        lab = (lg[:, 1] > lg[:, 0]).astype(np.int8)
+        assert np.array_equal(pred[offs[b]: offs[b + 1]], lab), (b, n)
+        assert np.array_equal(sm[offs[b]: offs[b + 1]], o.majority_voting(lab, window)), (b, n)
+        e_iv = o.smooth_label_region(lab, window, 13, 20)
+        assert niv[b] == len(e_iv) and [tuple(x) for x in iv[b, : niv[b]].tolist()] == e_iv, (b, n)
+        assert [tuple(x) for x in kp[b, : nk[b]].tolist()] == o.generate_unmaped_intervals(e_iv, n), (b, n)
 
 
 def test_smooth_properties_at_scale(env):
