@@ -920,9 +920,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   //      type 2 (fc2 k-tile): 32 A2 pieces [plane][4 octets][4 x 64 outputs]              -> 4 per wave
   //      piece `idx` of a wave is piece number wave + 8 * idx of the tile ----
   const uint32_t voff = lane * 16;
-#if defined(DC_M_PRIO)
-  __builtin_amdgcn_s_setprio(DC_M_PRIO);
-#endif
   // residual element of this lane's token in accumulator row `row_u + 4 h`: wave-uniform row base (scalar address
   // arithmetic) + one 32-bit per-lane element offset ((4 Tp + Tp) * 4 bytes < 2^32 for any batch that fits the HBM).
   const uint32_t xoff = (uint32_t)(4 * h) * (uint32_t)g.Tp + (uint32_t)(t_blk + t_w + i);
@@ -937,9 +934,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   auto issue_one = [&](int hc, int s, int slot, int idx) {
     const uint32_t base = lds0 + slot * M_SLOT;
     const int q = wave + 8 * idx;
-#if defined(DC_M_PRIO)
-    __builtin_amdgcn_s_setprio(0);  // A/B: the wave that issues an LDS-DMA piece yields the arbiter to its partner
-#endif
     if (s < M_T1) {
       if (idx < 2) {
         const int pl = q >> 3, o = (q >> 1) & 3, seg = q & 1;
@@ -955,9 +949,6 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
       const unsigned short* a2 = g.Wp2 + ((((int64_t)pl * N8 + oct) * M_D + seg * 64) << 3);
       glds16_s(a2, voff, base + ((pl * 4 + o) * M_D + seg * 64) * 16);
     }
-#if defined(DC_M_PRIO)
-    __builtin_amdgcn_s_setprio(DC_M_PRIO);
-#endif
   };
   auto n_pieces = [](int s) { return s < M_T1 ? 6 : 4; };
   auto issue_all = [&](int hc, int s, int slot) {
