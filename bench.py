@@ -215,7 +215,18 @@ def main():
         import torch.distributed as dist
 
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
-        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10), **kw)
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries exactly ONE JSON
+        # line, so file descriptor 1 points at stderr while the group forms (init + the first collective)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=10), **kw)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from deepchopper_amd import ops, synth
     from deepchopper_amd.model import DeepChopper
