@@ -166,8 +166,17 @@ def _merge_under_external_launcher(args, rank: int, world: int, part: str, parts
     from . import chop as chop_mod
 
     own = not dist.is_initialized()
-    if own:
-        dist.init_process_group("gloo")
+    if own:  # gloo announces its connections on stdout, which carries the output path: point fd 1 at stderr meanwhile
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     try:
         counts = [None] * world
         dist.all_gather_object(counts, (n_reads, n_records))
