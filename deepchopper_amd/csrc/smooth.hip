@@ -130,50 +130,40 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     const int64_t out_off = a.out_offsets ? a.out_offsets[r] : 0;
 
     // ---- S0: argmax (first max wins) -> label bits ------------------------------------
-    // One predicated form for full and partial chunks: all of a thread's loads are issued before the first compare.  (A
-    // byte-wise loop for the chunk that holds a read's end made ONE lane walk up to 15 dependent loads while its wave
-    // waited: most reads do not end on a multiple of 16.)
     for (int c = threadIdx.x; c < nch; c += BS) {
       const int p0 = 16 * c;
       unsigned m = 0;
-      if (FROM_LOGITS) {
-        float4 v[8];
+      if (p0 + 16 <= n) {
+        if (FROM_LOGITS) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int p = p0 + 2 * j;
-          v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p + 1 < n) {
-            __builtin_memcpy(&v[j], lg + 2 * (int64_t)p, 16);
-          } else if (p < n) {
-            const float2 t = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)p);
-            v[j].x = t.x;
-            v[j].y = t.y;
+          for (int j = 0; j < 8; ++j) {
+            float4 v;
+            __builtin_memcpy(&v, lg + 2 * (int64_t)p0 + 4 * j, 16);
+            m |= (v.y > v.x ? 1u : 0u) << (2 * j);  // class 1 only if strictly larger: ties -> 0
+            m |= (v.w > v.z ? 1u : 0u) << (2 * j + 1);
           }
+        } else {
+          uint4 v;
+          __builtin_memcpy(&v, lb + p0, 16);
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 16; ++k) m |= (((wv[k >> 2] >> (8 * (k & 3))) & 255u) == 1u ? 1u : 0u) << k;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          m |= (v[j].y > v[j].x ? 1u : 0u) << (2 * j);  // class 1 only if strictly larger: ties -> 0 (and 0 > 0 beyond n)
-          m |= (v[j].w > v[j].z ? 1u : 0u) << (2 * j + 1);
-        }
-      } else if (p0 + 16 <= n) {
-        uint4 v;
-        __builtin_memcpy(&v, lb + p0, 16);
-        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) m |= (((wv[k >> 2] >> (8 * (k & 3))) & 255u) == 1u ? 1u : 0u) << k;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (p0 + k < n) m |= (lb[p0 + k] == 1 ? 1u : 0u) << k;
-      }
-      if (FROM_LOGITS && a.pred) {
-        if (p0 + 16 <= n) {
+        if (FROM_LOGITS && a.pred) {
           const uint4 o = bits_to_bytes16(m);
           __builtin_memcpy(a.pred + out_off + p0, &o, 16);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (p0 + k < n) a.pred[out_off + p0 + k] = (m >> k) & 1u;
+        }
+      } else {
+        for (int k = 0; k < 16 && p0 + k < n; ++k) {
+          bool lab;
+          if (FROM_LOGITS) {
+            const float2 v = *reinterpret_cast<const float2*>(lg + 2 * (int64_t)(p0 + k));
+            lab = v.y > v.x;
+          } else {
+            lab = lb[p0 + k] == 1;
+          }
+          m |= (lab ? 1u : 0u) << k;
+          if (FROM_LOGITS && a.pred) a.pred[out_off + p0 + k] = lab ? 1 : 0;
         }
       }
       raw16[c] = (unsigned short)m;
@@ -232,9 +222,7 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
           const uint4 o = bits_to_bytes16(m);
           __builtin_memcpy(a.smooth + out_off + p0, &o, 16);
         } else {
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (p0 + k < n) a.smooth[out_off + p0 + k] = (m >> k) & 1u;
+          for (int k = 0; k < 16 && p0 + k < n; ++k) a.smooth[out_off + p0 + k] = (m >> k) & 1u;
         }
       }
     }
