@@ -156,7 +156,7 @@ def _launch_workers(args, argv: list[str]) -> int:
     return 0
 
 
-def _merge_under_external_launcher(args, rank: int, world: int, part: str, parts: list[str], n_reads: int, n_records: int,
+def _merge_under_external_launcher(args, rank: int, world: int, parts: list[str], n_reads: int, n_records: int,
                                    interleaved: bool) -> None:
     """`--chop` under torch.distributed.run (no parent of ours to merge): the ranks meet on a gloo group -- control
     plane only, a barrier and one gathered tuple -- and rank 0 splices the parts exactly as the self-launching parent
@@ -258,7 +258,7 @@ def _predict(args, argv: list[str]) -> int:
             _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                  args.ocq, chunks=chunks, part_path=parts[rank])
             dealt = check_compressed_type(str(data_path)) not in ("Uncompress", "Bgzip") or args.max_sample is not None
-            _merge_under_external_launcher(args, rank, world, parts[rank], parts, n_reads, n_records, dealt)
+            _merge_under_external_launcher(args, rank, world, parts, n_reads, n_records, dealt)
         else:
             final, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                      args.ocq, chunks=chunks)
