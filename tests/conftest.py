@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_oracle_threads():
+    """The CPU oracle (torch fp32) is the checker in these tests.  On a many-core host torch starts one thread per
+    hardware thread, and the small per-read oracle calls of the parity tests then spend their time in thread
+    hand-offs (bench.py's probe: 16 threads 30 reads/s, 256 threads 0.5): cap it at the GPU box's CPU share."""
+    import torch
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -324,6 +324,43 @@ def test_forward_ragged_mixed_lengths_config4(env):
         _check(out[b, stride - n:], ref)
 
 
+def test_forward_ragged_fuzz_one_handle_many_geometries(env):
+    """Seeded sweep: ONE handle sees a series of unrelated ragged batches (1 .. 80 reads; lengths around the 4-slot /
+    32-token / 1 024-token / FFT-threshold edges; workspace growing and shrinking; the cached geometry of an earlier
+    batch coming back), every batch checked read by read against the per-read oracle."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(2024)
+    edges = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 1026]
+    batches = []
+    for it in range(10):
+        n = int(rng.integers(1, 81))
+        lens = np.where(rng.random(n) < 0.35, rng.choice(edges, n), rng.integers(1, 420, n)).astype(np.int64)
+        if it in (3, 7):
+            lens[int(rng.integers(0, n))] = 2561 + int(rng.integers(0, 600))  # one read on the FFT path
+        batches.append(lens)
+    batches.append(batches[2].copy())  # same geometry key as an earlier batch, different contents
+    for it, lens in enumerate(batches):
+        B, stride = len(lens), int(lens.max())
+        ids = np.full((B, stride), 4, np.uint8)
+        q = np.zeros((B, stride), np.float32)
+        first = (stride - lens).astype(np.int32)
+        for b, n in enumerate(lens):
+            i1, q1 = _inputs(rng, 1, int(n))
+            ids[b, stride - n:] = i1[0]
+            q[b, stride - n:] = q1[0]
+        out = model.forward_ragged(ops.to_device(ids), ops.to_device(q), first, lens.astype(np.int32)).cpu().numpy()
+        assert np.isfinite(out).all()
+        # every short read, and the longest one
+        check = [b for b in range(B) if lens[b] <= 300][:40] + [int(np.argmax(lens))]
+        for b in check:
+            n = int(lens[b])
+            ref = fr.forward(sd, ids[b: b + 1, stride - n:].astype(np.int64), q[b: b + 1, stride - n:]).numpy()[0]
+            _check(out[b, stride - n:], ref)
+            assert np.all(out[b, : stride - n] == 0), f"batch {it}, read {b}: pad positions must stay zero"
+
+
 def test_fp16x3_range_guard_and_fallback(hip_lib):
     """An activation beyond the fp16 range must not silently corrupt the fp16x3 path: the kernels raise
     the overflow counter and the pipeline redoes the batch with the bf16 split."""
