@@ -27,6 +27,16 @@ class default:  # noqa: N801 - mirrors the PyO3 submodule name
     VECTORIZED_TARGET = False
 
 
+__all__ = [
+    "default", "Predict", "RecordData",
+    "encode_qual", "normalize_seq", "parse_target_from_id", "vectorize_target", "vectorize_targets",
+    "splite_qual_by_offsets", "seq_to_kmers", "seq_to_kmers_and_offset", "kmers_to_seq", "kmerids_to_seq",
+    "generate_kmers", "generate_kmers_table", "to_kmer_target_region", "to_original_targtet_region",
+    "encode_fq_path_to_tensor", "encode_fq_paths_to_tensor", "write_fq", "write_fq_parallel",
+    "majority_voting", "get_label_region", "smooth_label_region", "summary_predict",
+    "remove_intervals_and_keep_left", "id_list2seq", "load_predicts_from_batch_pt", "load_predicts_from_batch_pts",
+]
+
 MIN_READ_LEN = 150
 MIN_CHOPED_SEQ_LEN = 20
 IGNORE_LABEL = -100
@@ -297,6 +307,51 @@ def read_fastq(path: str) -> list[tuple[bytes, bytes, bytes]]:
             name = head[1:].rstrip(b"\r\n").split(b" ", 1)[0].split(b"\t", 1)[0]
             recs.append((name, seq, qual))
     return recs
+
+
+class RecordData:
+    """`RecordData(id, seq, qual)` (src/python.rs:93-160; src/fq_encode/record.rs:4-14).  The writers below also take
+    plain `(id, seq, qual)` tuples, as the reference's extractor does (src/python.rs:104-116)."""
+
+    __slots__ = ("id", "seq", "qual")
+
+    def __init__(self, id: str, seq: str, qual: str):  # noqa: A002 - the reference's argument name
+        self.id, self.seq, self.qual = id, seq, qual
+
+    def __repr__(self) -> str:
+        return f"RecordData(id={self.id!r}, seq={self.seq!r}, qual={self.qual!r})"
+
+
+def _record_bytes(rec) -> tuple[bytes, bytes, bytes]:
+    rid, seq, qual = (rec.id, rec.seq, rec.qual) if isinstance(rec, RecordData) else rec
+    return _b(rid), _b(seq), _b(qual)
+
+
+def write_fq(records_data, file_path=None) -> None:
+    """src/python.rs:171-178 -> src/output/writefq.rs:17-37: plain 4-line FASTQ ("@id", seq, "+", qual; the definition
+    carries no description) to `file_path`, or to stdout when it is None."""
+    import sys
+
+    sink = open(file_path, "wb") if file_path is not None else sys.stdout.buffer
+    try:
+        for rec in records_data:
+            rid, seq, qual = _record_bytes(rec)
+            sink.write(b"@" + rid + b"\n" + seq + b"\n+\n" + qual + b"\n")
+    finally:
+        if file_path is not None:
+            sink.close()
+        else:
+            sink.flush()
+
+
+def write_fq_parallel(records_data, file_path, threads: int) -> None:
+    """src/python.rs:180-192 -> write_zip_fq_parallel (src/output/writefq.rs:222-250): the same records through the
+    multithreaded BGZF writer (`threads` compression workers, at least one)."""
+    from .fastq import BgzfWriter
+
+    with BgzfWriter(str(file_path), threads=max(1, int(threads))) as w:
+        for rec in records_data:
+            w.write_record(*_record_bytes(rec))
 
 
 def tensor_encode_records(records, k: int, bases: bytes, qual_offset: int, vectorized_target: bool,

@@ -85,3 +85,53 @@ def test_no_cpu_mode_is_said_out_loud(tmp_path, capsys):
     fq.write_text("@r\nACGT\n+\nIIII\n")
     assert cli.main(["predict", str(fq), "-g", "0"]) == 1
     assert "no CPU fallback" in capsys.readouterr().err
+
+
+def test_import_name_of_the_reference_resolves_to_this_package():
+    """`import deepchopper` / `deepchopper.deepchopper` (the PyO3 module, src/python.rs:879-958) / `deepchopper.models`
+    / `python -m deepchopper`: the names a caller of the reference uses for this path."""
+    import subprocess
+    import sys
+
+    import deepchopper
+    import deepchopper_amd
+    from deepchopper.deepchopper import Predict, default, encode_qual, majority_voting  # noqa: F401
+    from deepchopper.models import DeepChopper
+
+    assert DeepChopper is deepchopper_amd.DeepChopper is deepchopper.DeepChopper
+    assert deepchopper.cli is cli and deepchopper.deepchopper is deepchopper_amd.rs_api
+    # `from .deepchopper import *` (deepchopper/__init__.py:4): the compiled module's names at top level
+    for name in ("encode_qual", "majority_voting", "smooth_label_region", "load_predicts_from_batch_pts", "Predict",
+                 "encode_fq_path_to_tensor", "write_fq", "write_fq_parallel", "RecordData"):
+        assert getattr(deepchopper, name) is getattr(deepchopper_amd.rs_api, name), name
+    assert (default.QUAL_OFFSET, default.BASES, default.KMER_SIZE, default.VECTORIZED_TARGET) == (33, "ATCGN", 3, False)
+    assert not hasattr(deepchopper, "train")  # outside this build: the name is simply absent
+    out = subprocess.run([sys.executable, "-m", "deepchopper", "--version"], cwd=ROOT, capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == f"DeepChopper Version: {deepchopper_amd.__version__}"
+
+
+def test_write_fq_and_write_fq_parallel(tmp_path):
+    """src/output/writefq.rs:17-37 (plain, "@id" without description) and :222-250 (multithreaded BGZF)."""
+    import gzip
+
+    from deepchopper_amd import rs_api
+    from deepchopper_amd.fastq import FastqReader
+
+    recs = [rs_api.RecordData("r1", "ACGT", "IIII"), ("r2|0:2|T", "AC", "#5"), rs_api.RecordData("r3", "N" * 70000, "!" * 70000)]
+    want = b"".join(b"@%s\n%s\n+\n%s\n" % tuple(x.encode() for x in ((r.id, r.seq, r.qual) if isinstance(r, rs_api.RecordData) else r))
+                    for r in recs)
+    plain = tmp_path / "a.fq"
+    rs_api.write_fq(recs, plain)
+    assert plain.read_bytes() == want
+    bg = tmp_path / "a.fq.gz"
+    rs_api.write_fq_parallel(recs, bg, 3)
+    assert gzip.open(bg, "rb").read() == want
+    raw = bg.read_bytes()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC"  # BGZF extra field
+    assert raw.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # EOF block
+    with FastqReader(str(bg)) as rd:
+        names = [n for c in rd.chunks(10, 1 << 20) for n in c.names()]
+    assert names == ["r1", "r2|0:2|T", "r3"]
+    r = recs[0]
+    r.seq = "TTTT"
+    assert (r.id, r.seq, r.qual) == ("r1", "TTTT", "IIII") and "TTTT" in repr(r)
