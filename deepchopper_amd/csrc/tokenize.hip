@@ -93,9 +93,13 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
     IdT* __restrict__ ids, float* __restrict__ quals, int8_t* __restrict__ labels,
     int32_t* __restrict__ n_tokens, int32_t* __restrict__ status) {
   __shared__ uint8_t s_tok[256];  // raw byte -> token id (0xFF = removed by normalize)
+  // phred value -> phred / norm of the wave's current read: a read has at most 256 distinct quotients, so the IEEE
+  // division (a dozen VALU instructions) runs 4 times per lane and read instead of once per base
+  __shared__ float s_quot[TK_WAVES][256];
   s_tok[threadIdx.x] = token_of_raw((uint8_t)threadIdx.x);
   __syncthreads();
   const int lane = threadIdx.x & 63;
+  float* const quot = s_quot[threadIdx.x >> 6];
   const int64_t total_bytes = offsets[n_reads];
   const int64_t wave0 = (int64_t)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * TK_WAVES;
@@ -172,6 +176,18 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
     // F.normalize(dim=0): x / max(||x||_2, 1e-12), fp32 (tokenizer.py:166).
     const float nrm = fmaxf(sqrtf((float)acc), 1e-12f);  // correctly rounded (hipcc default)
+    // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), once per phred value
+    {
+      float4 qq;
+      qq.x = (float)(4 * lane) / nrm;
+      qq.y = (float)(4 * lane + 1) / nrm;
+      qq.z = (float)(4 * lane + 2) / nrm;
+      qq.w = (float)(4 * lane + 3) / nrm;
+      __builtin_amdgcn_wave_barrier();  // the previous read's lookups are done (one wave: LDS operations are in order)
+      *reinterpret_cast<float4*>(quot + 4 * lane) = qq;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
 
     // pass 2: write the whole row: pad | tokens | [SEP] (| pad on the right when !pad_left)
 #pragma unroll 1
@@ -196,8 +212,7 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
             flags |= DC_READ_DROPPED_CHARS;
             t = 11;
           }
-          const float p = (float)((byte_of(qv, k) - qual_offset) & 255u);
-          q = p / nrm;  // IEEE division (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+          q = quot[(byte_of(qv, k) - qual_offset) & 255u];
           l = 0;
         } else if (i == len32) {
           t = DC_TOK_SEP;
