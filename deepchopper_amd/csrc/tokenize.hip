@@ -81,9 +81,10 @@ __global__ void encode_qual_kernel(const uint8_t* __restrict__ q, int64_t n, uin
 // of squares -> sqrtf -> IEEE division per base.
 constexpr int TK_WAVES = 4;  // reads per 256-thread workgroup
 
-__device__ __forceinline__ uint32_t byte_of(const uint4& v, int k) {
-  const uint32_t w = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
-  return (w >> (8 * (k & 3))) & 255u;
+// bit b of a nibble -> byte b of a word = 0xFF
+__device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t n) {
+  const uint32_t m = (n * 0x00204081u) & 0x01010101u;
+  return (m << 8) - m;
 }
 
 template <typename IdT>
@@ -92,14 +93,19 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
     int n_reads, int max_length, uint8_t qual_offset, int64_t row_stride, int pad_left,
     IdT* __restrict__ ids, float* __restrict__ quals, int8_t* __restrict__ labels,
     int32_t* __restrict__ n_tokens, int32_t* __restrict__ status) {
-  __shared__ uint8_t s_tok[256];  // raw byte -> token id (0xFF = removed by normalize)
+  __shared__ uint8_t s_tok[256];  // raw byte -> token id (| 0x80: removed by normalize, see below)
   // phred value -> phred / norm of the wave's current read: a read has at most 256 distinct quotients, so the IEEE
   // division (a dozen VALU instructions) runs 4 times per lane and read instead of once per base
   __shared__ float s_quot[TK_WAVES][256];
-  s_tok[threadIdx.x] = token_of_raw((uint8_t)threadIdx.x);
+  {
+    const uint8_t t = token_of_raw((uint8_t)threadIdx.x);
+    s_tok[threadIdx.x] = t == 0xFF ? uint8_t(0x80 | 11) : t;  // bit 7: removed by normalize, counted as token 11
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   float* const quot = s_quot[threadIdx.x >> 6];
+  __shared__ uint32_t s_xch[TK_WAVES][256];  // a wave's phred bytes of one step, changing lanes for the quality stores
+  uint32_t* const xch = s_xch[threadIdx.x >> 6];
   const int64_t total_bytes = offsets[n_reads];
   const int64_t wave0 = (int64_t)blockIdx.x * TK_WAVES + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * TK_WAVES;
@@ -141,16 +147,57 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
       }
       return v;
     };
+    // Word-wise ("SWAR") handling of a 16-byte chunk.  Only the lane that holds a read's end (or, with left padding, its
+    // start) has partly valid chunks, but a SIMD runs every lane's instructions: per-byte compares and selects were
+    // most of this kernel (~55 instructions per base; without its stores it still took 0.115 of 0.165 ms).  Instead the
+    // validity of a chunk's bytes becomes four byte masks, computed once, and invalid bytes are replaced up front by
+    // values that produce the right result on their own: quality byte = qual_offset (phred 0 -> quotient 0, nothing
+    // added to the sum of squares, no underflow), token word merged with the pad word by one v_bfi, label word = ~valid
+    // & 0x9C9C9C9C (-100).
+    struct Chunk {
+      uint32_t valid[4];  // byte masks: source index inside [0, len)
+      uint32_t sep[4];    //             source index == len  ([SEP])
+    };
+    auto chunk_masks = [&](int i0) -> Chunk {
+      int k_lo = -i0, k_hi = len32 - i0;  // valid k: [k_lo, k_hi) /\ [0, 16)
+      k_lo = k_lo < 0 ? 0 : k_lo > 16 ? 16 : k_lo;
+      const int k_sep = k_hi;
+      k_hi = k_hi < k_lo ? k_lo : k_hi > 16 ? 16 : k_hi;
+      const uint32_t vbits = ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+      const uint32_t sbits = (unsigned)k_sep < 16u ? 1u << k_sep : 0u;
+      Chunk c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c.valid[j] = nibble_to_bytes((vbits >> (4 * j)) & 15u);
+        c.sep[j] = nibble_to_bytes((sbits >> (4 * j)) & 15u);
+      }
+      return c;
+    };
+    const uint32_t qoff4 = 0x01010101u * qual_offset;
+    auto mask_quals = [&](const Chunk& c, const uint4& qv, uint32_t (&qm)[4]) {  // invalid bytes -> qual_offset; underflow flag
+      const uint32_t q[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) qm[j] = (q[j] & c.valid[j]) | (qoff4 & ~c.valid[j]);
+      if (qual_offset <= 128) {  // "a byte of x is below n" for n <= 128, word-wise
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) any |= (qm[j] - qoff4) & ~qm[j] & 0x80808080u;
+        if (any) flags |= DC_READ_QUAL_UNDERFLOW;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (((qm[k >> 2] >> (8 * (k & 3))) & 255u) < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
+      }
+    };
+    auto phred = [&](const uint32_t (&qm)[4], int k) -> unsigned { return (((qm[k >> 2] >> (8 * (k & 3))) & 255u) - qual_offset) & 255u; };
     auto sumsq16 = [&](int i0, const uint4& qv) -> unsigned {  // over [i0, i0 + 16) /\ [0, len)
+      uint32_t qm[4];
+      mask_quals(chunk_masks(i0), qv, qm);
       unsigned sacc = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const uint32_t qb = byte_of(qv, k);
-        if ((unsigned)(i0 + k) < (unsigned)len32) {
-          if (qb < qual_offset) flags |= DC_READ_QUAL_UNDERFLOW;
-          const unsigned p = (qb - qual_offset) & 255u;
-          sacc += p * p;  // 16 x 255^2 < 2^32
-        }
+        const unsigned ph = phred(qm, k);
+        sacc += ph * ph;  // 16 x 255^2 < 2^32
       }
       return sacc;
     };
@@ -189,71 +236,78 @@ __global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
       __builtin_amdgcn_wave_barrier();
     }
 
-    // pass 2: write the whole row: pad | tokens | [SEP] (| pad on the right when !pad_left)
+    // pass 2: write the whole row: pad | tokens | [SEP] (| pad on the right when !pad_left), 1 024 columns per step.
+    // Tokens and labels are a byte per column: a lane's 16 and the wave's 1 024 bytes are contiguous.  The fp32
+    // qualities of a lane's 16 columns are 64 bytes -- four stores of 16 bytes each, which from every lane at once are
+    // four stores with a stride of 64 bytes, a quarter of every line per instruction.  So the phred bytes change lanes
+    // first (a 1 KiB exchange through LDS: lane l hands over its 16, takes 4 x 4 from lanes 16 k + l / 4): store k of
+    // lane l then covers columns 256 k + 4 l .. + 3, and one instruction of the wave writes 1 KiB in a piece.
 #pragma unroll 1
-    for (int c0 = 16 * lane; c0 < stride32; c0 += 16 * 64) {
+    for (int cbase = 0; cbase < stride32; cbase += 16 * 64) {
+      const int c0 = cbase + 16 * lane;
       const int i0 = c0 - pad;  // source index of the chunk's first column
       if (!one_step) {
         sv = load16(seq, i0);
         qv = load16(qual, i0);
       }
-      uint32_t tok[16];
-      float qf[16];
-      uint32_t lab[16];
+      const Chunk cm = chunk_masks(i0);
+      uint32_t qm[4];
+      mask_quals(cm, qv, qm);
+      __builtin_amdgcn_wave_barrier();  // (one wave: LDS operations are in order; the barriers only pin the compiler)
+      *reinterpret_cast<uint4*>(xch + 4 * lane) = make_uint4(qm[0], qm[1], qm[2], qm[3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t sw[4] = {sv.x, sv.y, sv.z, sv.w};
+      uint32_t tokw[4], labw[4];
+      uint32_t dropped = 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int i = i0 + k;
-        uint32_t t = DC_TOK_PAD;
-        float q = 0.0f;
-        uint32_t l = (uint32_t)(uint8_t)DC_IGNORE_LABEL;
-        if ((unsigned)i < (unsigned)len32) {
-          t = s_tok[byte_of(sv, k)];
-          if (t == 0xFFu) {
-            flags |= DC_READ_DROPPED_CHARS;
-            t = 11;
-          }
-          q = quot[(byte_of(qv, k) - qual_offset) & 255u];
-          l = 0;
-        } else if (i == len32) {
-          t = DC_TOK_SEP;
-        }
-        tok[k] = t;
-        qf[k] = q;
-        lab[k] = l;
+      for (int j = 0; j < 4; ++j) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w |= (uint32_t)s_tok[(sw[j] >> (8 * b)) & 255u] << (8 * b);
+        dropped |= w & cm.valid[j] & 0x80808080u;
+        w &= 0x7F7F7F7Fu;
+        w = (w & cm.valid[j]) | ((0x01010101u * DC_TOK_PAD) & ~cm.valid[j]);
+        tokw[j] = (w & ~cm.sep[j]) | ((0x01010101u * DC_TOK_SEP) & cm.sep[j]);
+        labw[j] = ~cm.valid[j] & (0x01010101u * (uint32_t)(uint8_t)DC_IGNORE_LABEL);
       }
+      if (dropped) flags |= DC_READ_DROPPED_CHARS;
       if (c0 + 16 <= stride32) {
         if (sizeof(IdT) == 1) {
-          uint4 o;
-          o.x = tok[0] | tok[1] << 8 | tok[2] << 16 | tok[3] << 24;
-          o.y = tok[4] | tok[5] << 8 | tok[6] << 16 | tok[7] << 24;
-          o.z = tok[8] | tok[9] << 8 | tok[10] << 16 | tok[11] << 24;
-          o.w = tok[12] | tok[13] << 8 | tok[14] << 16 | tok[15] << 24;
+          const uint4 o = make_uint4(tokw[0], tokw[1], tokw[2], tokw[3]);
           __builtin_memcpy(id_row + c0, &o, 16);
         } else {
 #pragma unroll
           for (int k = 0; k < 16; k += 2) {
-            const ulonglong2 o = make_ulonglong2(tok[k], tok[k + 1]);
+            const ulonglong2 o = make_ulonglong2((tokw[k >> 2] >> (8 * (k & 3))) & 255u, (tokw[k >> 2] >> (8 * ((k + 1) & 3))) & 255u);
             __builtin_memcpy(id_row + c0 + k, &o, 16);
           }
         }
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-          const float4 o = make_float4(qf[k], qf[k + 1], qf[k + 2], qf[k + 3]);
-          __builtin_memcpy(q_row + c0 + k, &o, 16);
-        }
         if (l_row) {
-          uint4 o;
-          o.x = lab[0] | lab[1] << 8 | lab[2] << 16 | lab[3] << 24;
-          o.y = lab[4] | lab[5] << 8 | lab[6] << 16 | lab[7] << 24;
-          o.z = lab[8] | lab[9] << 8 | lab[10] << 16 | lab[11] << 24;
-          o.w = lab[12] | lab[13] << 8 | lab[14] << 16 | lab[15] << 24;
+          const uint4 o = make_uint4(labw[0], labw[1], labw[2], labw[3]);
           __builtin_memcpy(l_row + c0, &o, 16);
         }
-      } else {  // the row ends inside this chunk: the next row belongs to another wave
+      } else {  // the row ends inside this chunk (the next row belongs to another wave), or in front of it
         for (int k = 0; k < 16 && c0 + k < stride32; ++k) {
-          id_row[c0 + k] = (IdT)tok[k];
-          q_row[c0 + k] = qf[k];
-          if (l_row) l_row[c0 + k] = (int8_t)lab[k];
+          id_row[c0 + k] = (IdT)((tokw[k >> 2] >> (8 * (k & 3))) & 255u);
+          if (l_row) l_row[c0 + k] = (int8_t)((labw[k >> 2] >> (8 * (k & 3))) & 255u);
+        }
+      }
+      // qualities: invalid bytes carry qual_offset, i.e. phred 0 -> 0 / norm = 0
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t w = xch[64 * k + lane];
+        const int col = cbase + 256 * k + 4 * lane;
+        float4 o;
+        o.x = quot[((w & 255u) - qual_offset) & 255u];
+        o.y = quot[(((w >> 8) & 255u) - qual_offset) & 255u];
+        o.z = quot[(((w >> 16) & 255u) - qual_offset) & 255u];
+        o.w = quot[((w >> 24) - qual_offset) & 255u];
+        if (col + 4 <= stride32) {
+          __builtin_memcpy(q_row + col, &o, 16);
+        } else {
+          const float e[4] = {o.x, o.y, o.z, o.w};
+          for (int b = 0; b < 4 && col + b < stride32; ++b) q_row[col + b] = e[b];
         }
       }
     }
