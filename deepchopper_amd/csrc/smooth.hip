@@ -90,6 +90,10 @@ __device__ __forceinline__ int run_start(const unsigned long long* words, int i)
   }
 }
 
+#ifndef SM_S0_BATCH
+#define SM_S0_BATCH 4
+#endif
+
 // 16 label bits -> 16 bytes of 0 / 1
 __device__ __forceinline__ uint4 bits_to_bytes16(unsigned m) {
   auto q = [](unsigned x) { return (x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21); };
@@ -110,6 +114,9 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
   __shared__ int s_iv[2 * SM_LDS_IV];  // the first kept intervals, for the complement step (no global round trip)
   unsigned short* raw16 = reinterpret_cast<unsigned short*>(s_raw);  // chunk c = bits [16 (c & 3), +16) of word c >> 2
   unsigned short* sm16 = reinterpret_cast<unsigned short*>(s_sm);
+  // logits mode: per wave, the 2-bit results of one stripe of 1 024 positions on their way from the lanes that loaded
+  // them to the lanes that own their chunks
+  __shared__ __attribute__((aligned(8))) unsigned char s_xb[FROM_LOGITS ? BS / 64 : 1][512];
 
   for (int r = blockIdx.x; r < a.n_reads; r += gridDim.x) {
     int n;
@@ -130,6 +137,54 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     const int64_t out_off = a.out_offsets ? a.out_offsets[r] : 0;
 
     // ---- S0: argmax (first max wins) -> label bits ------------------------------------
+    // Logits: a chunk of 16 positions is 128 bytes, so "one chunk per lane" meant eight 16-byte loads per lane with a
+    // lane stride of 128 bytes -- every instruction touched 64 lines for 16 bytes each, and with 28 waves per CU the lines
+    // did not survive in the 32 KiB L1 until their next 16 bytes were asked for: L2 -> L1 moved each line up to eight
+    // times (ablating the loads took 37 % off the kernel).  Now a wave walks a stripe of 1 024 positions with eight
+    // loads of 1 KiB each (lane l of load j: positions 128 j + 2 l, + 1), and the two label bits of a lane and load go
+    // through a 512-byte LDS array to the lane that owns their chunk: byte 64 j + l = 8 c + t holds bits 2 t, 2 t + 1 of
+    // chunk c, which reads its eight bytes back as one 64-bit word and squeezes them to 16 bits with two multiplies.
+    if (FROM_LOGITS && n >= 2) {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      unsigned char* xb = s_xb[wv];
+      for (int st = wv; st * 1024 < n; st += BS / 64) {  // wave-uniform
+        const int P = st * 1024;
+        __builtin_amdgcn_wave_barrier();  // the previous stripe's bytes have been read (one wave: LDS operations are in order)
+#pragma unroll
+        for (int jb = 0; jb < 8; jb += SM_S0_BATCH) {  // loads in flight together (all eight cost 32 registers and a wave per SIMD)
+          float4 v[SM_S0_BATCH];
+#pragma unroll
+          for (int j = 0; j < SM_S0_BATCH; ++j) {
+            const int pos = P + 128 * (jb + j) + 2 * lane;
+            const int pa = pos < n - 2 ? pos : n - 2;  // clamped into the read (results of clamped lanes are masked below)
+            __builtin_memcpy(&v[j], lg + 2 * (int64_t)pa, 16);
+          }
+#pragma unroll
+          for (int j = 0; j < SM_S0_BATCH; ++j) {
+            const int pos = P + 128 * (jb + j) + 2 * lane;
+            const unsigned a0 = v[j].y > v[j].x ? 1u : 0u, a1 = v[j].w > v[j].z ? 1u : 0u;  // class 1 only if strictly larger: ties -> 0
+            // pos + 1 < n: both positions are this lane's; pos == n - 1: the clamped load holds it in its second half
+            const unsigned two = pos + 1 < n ? (a0 | a1 << 1) : pos < n ? a1 : 0u;
+            xb[64 * (jb + j) + lane] = (unsigned char)two;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long x = *reinterpret_cast<const unsigned long long*>(xb + 8 * lane);
+        // bytes b0 .. b3 (two bits each) of a 32-bit half -> b0 | b1 << 2 | b2 << 4 | b3 << 6 in the product's top byte
+        const unsigned m = (((unsigned)x * 0x01041040u) >> 24) | ((((unsigned)(x >> 32) * 0x01041040u) >> 24) << 8);
+        const int c = 64 * st + lane, p0 = 16 * c;
+        if (c < nch) raw16[c] = (unsigned short)m;
+        if (a.pred) {
+          if (p0 + 16 <= n) {
+            const uint4 o = bits_to_bytes16(m);
+            __builtin_memcpy(a.pred + out_off + p0, &o, 16);
+          } else {
+            for (int k = 0; k < 16 && p0 + k < n; ++k) a.pred[out_off + p0 + k] = (m >> k) & 1u;
+          }
+        }
+      }
+    } else
     for (int c = threadIdx.x; c < nch; c += BS) {
       const int p0 = 16 * c;
       unsigned m = 0;

@@ -49,7 +49,17 @@ res["tokenize_batch_kernel"] = {"ms": round(ms, 4), "algorithmic_bytes": n * bp 
 ms = timed(lambda: ops.kmer_encode(d_seq, d_qual, offs, rows, n, k, bases, 33, bp - k + 1, bp))
 res["kmer_encode_kernel"] = {"ms": round(ms, 4), "algorithmic_bytes": n * bp * 14, "note": "2 B in + 2 x 4 B k-mer rows + 4 B full-phred row per base"}
 ms = timed(lambda: ops.smooth_intervals_from_logits(logits, first, length, want_labels=True, out_offsets=out_off, total=n * bp))
-res["smooth_kernel<true>"] = {"ms": round(ms, 4), "algorithmic_bytes": n * bp * 10, "note": "8 B logits in + 1 B label + 1 B smoothed label out per base"}
+res["smooth_kernel<true>"] = {"ms": round(ms, 4), "algorithmic_bytes": n * bp * 10,
+                              "note": "8 B logits in + 1 B label + 1 B smoothed label out per base; logits are white noise: half the labels "
+                                      "are ones and a read has dozens of runs (the worst case for the run / interval phases)"}
+# SURVEY 8d's label stream (Bernoulli(0.02) noise + planted runs of geometric length, mean 60; seed 43) as logits with a margin
+lab = synth.synth_label_stream(n * (bp + 1), seed=43).reshape(n, bp + 1)
+logits[..., 1] = torch.from_numpy(np.where(lab == 1, 1.0, -1.0).astype(np.float32)).cuda() + 0.25 * logits[..., 1].clamp(-2, 2)
+logits[..., 0] = 0.25 * logits[..., 0].clamp(-2, 2)
+del lab
+ms = timed(lambda: ops.smooth_intervals_from_logits(logits, first, length, want_labels=True, out_offsets=out_off, total=n * bp))
+res["smooth_kernel<true>, SURVEY 8d label stream"] = {"ms": round(ms, 4), "algorithmic_bytes": n * bp * 10,
+                                                      "note": "same traffic; labels = Bernoulli(0.02) noise + planted runs (mean 60), seed 43"}
 for v in res.values():
     v["GB_per_s"] = round(v["algorithmic_bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
     v["frac_of_8TBps"] = round(v["GB_per_s"] / 8000, 4)
