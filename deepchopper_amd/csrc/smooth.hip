@@ -225,38 +225,70 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     }
     __syncthreads();
     const int w = a.window, h = w >> 1;
-    if (w > 31) word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);  // only the general window form counts through prefixes
+    const bool short_window = h >= 1 && w <= 31;
+    if (!short_window) word_prefix<BS, CAPW>(s_raw, nw, s_pref, s_scratch);  // the general window form counts through prefixes
 
     // ---- S1: majority_voting (smooth/utils.rs:48-97) -----------------------------------
-    for (int c = threadIdx.x; c < nch; c += BS) {
-      const int p0 = 16 * c;
-      unsigned m = 0;
-      if (w <= 31) {
-        // every window of the chunk lies inside positions [p0 - 32, p0 + 32): four 16-bit pieces of the bit-vector, held
-        // as two 32-bit halves so that a window is one funnel shift (v_alignbit) + and + popcount, all full-rate 32-bit
-        // operations (64-bit shifts run at a quarter of the rate)
+    if (short_window) {
+      // Windows of at most 31 positions.  Away from the read's ends the window of position i is [i - h, i + h]: 2 h + 1
+      // positions, odd, so no tie and no clamping -- a funnel shift, an and, a popcount and one compare per position.
+      // Every lane runs that form on all 16 positions of its chunk (zero bits stand in beyond the ends); the at most
+      // 2 h positions whose window is cut by an end of the read (i < h, i >= n - h: clamped start / end, the
+      // "end == n" re-anchoring, ties) are then redone with the general rule, ONE position per lane of the first wave,
+      // and patched into the bit-vector -- instead of every lane dragging the general rule through all its positions
+      // for the sake of one or two lanes (~20 instructions per position, a sixth of the kernel).
+      const unsigned mask_w = (1u << (2 * h + 1)) - 1u;
+      for (int c = threadIdx.x; c < nch; c += BS) {
+        // positions [16 c - 32, 16 c + 32) of the bit-vector as two 32-bit halves, shifted so that bit k is position 16 c + k - h
         const unsigned lo = (c >= 2 ? (unsigned)raw16[c - 2] : 0u) | (c >= 1 ? (unsigned)raw16[c - 1] << 16 : 0u);
         const unsigned hi = (unsigned)raw16[c] | (c + 1 < nch ? (unsigned)raw16[c + 1] << 16 : 0u);
-        const int base = p0 - 32;
+        const unsigned x_lo = __builtin_amdgcn_alignbit(hi, lo, 32u - (unsigned)h), x_hi = hi >> (32u - (unsigned)h);
+        unsigned m = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          const int i = p0 + k;
-          if (i < n) {
-            int start = i - h < 0 ? 0 : i - h;
-            int end = i + h + 1 > n ? n : i + h + 1;
-            if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
-            const int ln = end - start;                    // 1 .. 31
-            const unsigned sft = (unsigned)(start - base);  // 0 .. 47
-            const unsigned win = sft < 32u ? __builtin_amdgcn_alignbit(hi, lo, sft) : hi >> (sft - 32u);
-            const int ones = __popc(win & ((1u << ln) - 1u));
-            bool sm;
-            if (2 * ones > ln) sm = true;
-            else if (2 * ones < ln) sm = false;
-            else sm = (hi >> k) & 1u;
-            if (sm) m |= 1u << k;
+          const unsigned win = k == 0 ? x_lo : __builtin_amdgcn_alignbit(x_hi, x_lo, (unsigned)k);
+          m |= (__popc(win & mask_w) > h ? 1u : 0u) << k;
+        }
+        sm16[c] = (unsigned short)m;
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        const int n_left = h < n ? h : n;                      // positions 0 .. n_left - 1
+        const int r0 = n - h > n_left ? n - h : n_left;        // positions r0 .. n - 1
+        const int n_right = n - r0;
+        const int i = l < n_left ? l : r0 + (l - n_left);
+        bool sm = false;
+        if (l < n_left + n_right) {
+          int start = i - h < 0 ? 0 : i - h;
+          int end = i + h + 1 > n ? n : i + h + 1;
+          if (end == n && (end - start) < w) start = end - w < 0 ? 0 : end - w;
+          const int ln = end - start;  // 1 .. 31
+          const unsigned* raw32 = reinterpret_cast<const unsigned*>(s_raw);
+          const int wi = start >> 5;
+          const unsigned b_lo = raw32[wi], b_hi = wi + 1 < 2 * CAPW ? raw32[wi + 1] : 0u;
+          const unsigned win = __builtin_amdgcn_alignbit(b_hi, b_lo, (unsigned)(start & 31));
+          const int ones = __popc(win & ((1u << ln) - 1u));
+          if (2 * ones > ln) sm = true;
+          else if (2 * ones < ln) sm = false;
+          else sm = bit_at(s_raw, i);
+        }
+        const unsigned long long bal = __ballot(sm);
+        if (l == 0 && n > 0) {
+          const unsigned long long m_left = (1ull << n_left) - 1ull, m_right = (1ull << n_right) - 1ull;  // < 16 bits each
+          s_sm[0] = (s_sm[0] & ~m_left) | (bal & m_left);
+          if (n_right > 0) {
+            const unsigned long long bits = (bal >> n_left) & m_right;
+            const int wr = r0 >> 6, sr = r0 & 63;
+            s_sm[wr] = (s_sm[wr] & ~(m_right << sr)) | (bits << sr);
+            if (sr + n_right > 64) s_sm[wr + 1] = (s_sm[wr + 1] & ~(m_right >> (64 - sr))) | (bits >> (64 - sr));
           }
         }
-      } else {
+      }
+    } else {
+      for (int c = threadIdx.x; c < nch; c += BS) {
+        const int p0 = 16 * c;
+        unsigned m = 0;
         for (int k = 0; k < 16 && p0 + k < n; ++k) {
           const int i = p0 + k;
           int start = i - h < 0 ? 0 : i - h;
@@ -270,15 +302,7 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
           else sm = bit_at(s_raw, i);
           if (sm) m |= 1u << k;
         }
-      }
-      sm16[c] = (unsigned short)m;
-      if (a.smooth) {
-        if (p0 + 16 <= n) {
-          const uint4 o = bits_to_bytes16(m);
-          __builtin_memcpy(a.smooth + out_off + p0, &o, 16);
-        } else {
-          for (int k = 0; k < 16 && p0 + k < n; ++k) a.smooth[out_off + p0 + k] = (m >> k) & 1u;
-        }
+        sm16[c] = (unsigned short)m;
       }
     }
     __syncthreads();
@@ -289,6 +313,15 @@ __global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
     // their run's start
     for (int c = threadIdx.x; c < nch; c += BS) {
       const unsigned m = sm16[c];
+      if (a.smooth) {
+        const int p0 = 16 * c;
+        if (p0 + 16 <= n) {
+          const uint4 o = bits_to_bytes16(m);
+          __builtin_memcpy(a.smooth + out_off + p0, &o, 16);
+        } else {
+          for (int k = 0; k < 16 && p0 + k < n; ++k) a.smooth[out_off + p0 + k] = (m >> k) & 1u;
+        }
+      }
       const unsigned nxt = c + 1 < nch ? (sm16[c + 1] & 1u) : 0u;
       unsigned ends = m & ~((m >> 1) | (nxt << 15));
       unsigned kept = 0;
