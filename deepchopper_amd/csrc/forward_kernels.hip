@@ -2053,16 +2053,18 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   DC_STAMP_T(st2);
   // ---- epilogue: C[read][q'] -> patch -> row-wise: y = conv * sf(x0), 16 B per lane ----
   // (all waves passed the last barrier: the filter window is dead, each wave takes a 32 x 33 patch of it)
-  float* patch = reinterpret_cast<float*>(s_filt) + wave * (32 * 33);
+  // Row stride 36 floats: rows are 16-byte aligned, so the gated products go back into the patch and out again as
+  // 16-byte LDS accesses (see the stores below).
+  constexpr int PS = 36;
+  static_assert(4 * 32 * PS * 4 <= h3_filt_bytes(NP), "the four epilogue patches alias the filter window");
+  float* patch = reinterpret_cast<float*>(s_filt) + wave * (32 * PS);
   const int er = lane >> 1, eh = (lane & 1) * 16;  // read-back: read er, steps eh .. eh+15
   int re = a.grp_reads[g * 32 + er];
   const bool e_valid = re >= 0;
   if (!e_valid) re = a.grp_reads[g * 32];
   const int64_t e_off = a.toff[re];
   const int e_nblk = e_valid ? a.nblk[re] : 0;
-  const int e_nt4 = e_valid ? (a.ntok[re] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
   const float* ux0 = a.u + (int64_t)c * a.Tp + e_off;
-  float* yrow = a.y + (int64_t)c * a.Tp + e_off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
   const float inv_sc = MODE == 1 ? a.ch_inv_scale[c] : 1.0f;  // fp16x3: undo the filter's power-of-two scale
   if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
@@ -2092,6 +2094,20 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 #pragma unroll
       for (int b = 0; b < 4; ++b) w[4 * j + b] = tab_at(0, ids[j], b);
   };
+  // Stores: with "lane = (read, 16 tokens)" a lane's 64 bytes leave as four stores at a lane stride of 64 bytes -- every
+  // instruction writes a quarter of each 128-byte line it touches (the same pattern cost tokenize_batch_kernel 29 %).
+  // So the gated products return to the patch and are read back as "8 lanes = the 32 tokens of one read": store i of
+  // the wave covers reads 8 i .. 8 i + 7 of the group, each with one full line.
+  const int sq = (lane & 7) * 4, srs = lane >> 3;
+  int s_off[4], s_nblk[4], s_nt4[4];  // per store i: the read's slot offset / blocks / owned slots (0: no such read)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = a.grp_reads[g * 32 + 8 * i + srs];
+    s_off[i] = rr >= 0 ? (int)a.toff[rr] : 0;
+    s_nblk[i] = rr >= 0 ? a.nblk[rr] : 0;
+    s_nt4[i] = rr >= 0 ? (a.ntok[rr] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
+  }
+  float* const ychan = a.y + (int64_t)c * a.Tp;
   float wq[2][20];
   {
     const int pp0 = p_out0 + wave;
@@ -2108,22 +2124,34 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     }
     if (pp <= p_out_last) {  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r32] = acc[m][e];
+      for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * PS + r32] = acc[m][e];
       if (pp < e_nblk) {
-        const int64_t t0 = 32 * pp + eh;
         float(&w)[20] = wq[m & 1];
         expand_win(w);
-        float o[16];
+        float4* prow = reinterpret_cast<float4*>(patch + er * PS + eh);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const float gate = fmaf(wx0_0, w[s + 2], fmaf(wx0_1, w[s + 3], fmaf(wx0_2, w[s + 4], bx0)));
-          o[s] = patch[er * 33 + eh + s] * inv_sc * gate;
+        for (int j = 0; j < 4; ++j) {
+          float4 v = prow[j];
+          const int s = 4 * j;
+          v.x *= inv_sc * fmaf(wx0_0, w[s + 2], fmaf(wx0_1, w[s + 3], fmaf(wx0_2, w[s + 4], bx0)));
+          v.y *= inv_sc * fmaf(wx0_0, w[s + 3], fmaf(wx0_1, w[s + 4], fmaf(wx0_2, w[s + 5], bx0)));
+          v.z *= inv_sc * fmaf(wx0_0, w[s + 4], fmaf(wx0_1, w[s + 5], fmaf(wx0_2, w[s + 6], bx0)));
+          v.w *= inv_sc * fmaf(wx0_0, w[s + 5], fmaf(wx0_1, w[s + 6], fmaf(wx0_2, w[s + 7], bx0)));
+          prow[j] = v;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (t0 + 4 * j < e_nt4)
-            *reinterpret_cast<float4*>(yrow + t0 + 4 * j) = make_float4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
       }
+      // (one wave: LDS operations are in order; the fence only pins the compiler)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int ts = 32 * pp + sq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (pp < s_nblk[i] && ts < s_nt4[i]) {
+          const float4 v = *reinterpret_cast<const float4*>(patch + (8 * i + srs) * PS + sq);
+          *reinterpret_cast<float4*>(ychan + s_off[i] + ts) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the next block's accumulators overwrite the patch
     }
   }
 #ifdef DC_STAMP
