@@ -2051,55 +2051,21 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   }
 
   DC_STAMP_T(st2);
-  // ---- epilogue: C[read][q'] -> patch -> row-wise: y = conv * sf(x0), 16 B per lane ----
-  // (all waves passed the last barrier: the filter window is dead, each wave takes a 32 x 33 patch of it)
-  // Row stride 36 floats: rows are 16-byte aligned, so the gated products go back into the patch and out again as
-  // 16-byte LDS accesses (see the stores below).
+  // ---- epilogue: C[read][q'] -> patch -> y = conv * sf(x0), a full 128-byte line per read and instruction ----
+  // (all waves passed the last barrier: the filter window is dead, each wave takes a 32 x 36 patch of it)
+  // Lane = (read 8 i + lane / 8 of the group, tokens 4 (lane % 8) .. + 3 of the output block), i = 0 .. 3: eight lanes
+  // hold the 32 tokens of one read, so every x0 load and every y store of the wave moves whole lines.  The first form
+  // gave a lane 16 tokens of one read: its loads and stores were 16-byte pieces at a lane stride of 64 bytes, a quarter
+  // of each line per instruction (the same pattern cost tokenize_batch_kernel 29 %; here 2.27 -> 2.17 ms for the
+  // stores, -> 2.1x for the loads as well).  Patch rows are 36 floats: 16-byte aligned for the read-back.
   constexpr int PS = 36;
   static_assert(4 * 32 * PS * 4 <= h3_filt_bytes(NP), "the four epilogue patches alias the filter window");
   float* patch = reinterpret_cast<float*>(s_filt) + wave * (32 * PS);
-  const int er = lane >> 1, eh = (lane & 1) * 16;  // read-back: read er, steps eh .. eh+15
-  int re = a.grp_reads[g * 32 + er];
-  const bool e_valid = re >= 0;
-  if (!e_valid) re = a.grp_reads[g * 32];
-  const int64_t e_off = a.toff[re];
-  const int e_nblk = e_valid ? a.nblk[re] : 0;
-  const float* ux0 = a.u + (int64_t)c * a.Tp + e_off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
   const float inv_sc = MODE == 1 ? a.ch_inv_scale[c] : 1.0f;  // fp16x3: undo the filter's power-of-two scale
   if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
-  // x0 windows are requested one output block ahead of their use: fetched when needed, each of the (up to) eight
-  // blocks of a wave paid a full memory round trip (a quarter of the kernel was this epilogue)
-  const unsigned char* tke = TAB ? a.tok + e_off : nullptr;
-  // TAB: a window is 5 dwords of token ids (positions t0-4 .. t0+15), expanded through the table at its use
-  auto load_win = [&](int64_t t0, bool has_prev, bool active, float (&w)[20]) {
-    if (!TAB) {
-      load_window20(ux0, t0, has_prev, active, w);
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      uint32_t ids = 0xFFFFFFFFu;
-      if (active && (j > 0 || has_prev)) ids = *reinterpret_cast<const uint32_t*>(tke + t0 - 4 + 4 * j);
-      w[j] = __builtin_bit_cast(float, ids);
-    }
-  };
-  auto expand_win = [&](float (&w)[20]) {
-    if (!TAB) return;
-    uint32_t ids[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) ids[j] = __builtin_bit_cast(uint32_t, w[j]);
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) w[4 * j + b] = tab_at(0, ids[j], b);
-  };
-  // Stores: with "lane = (read, 16 tokens)" a lane's 64 bytes leave as four stores at a lane stride of 64 bytes -- every
-  // instruction writes a quarter of each 128-byte line it touches (the same pattern cost tokenize_batch_kernel 29 %).
-  // So the gated products return to the patch and are read back as "8 lanes = the 32 tokens of one read": store i of
-  // the wave covers reads 8 i .. 8 i + 7 of the group, each with one full line.
   const int sq = (lane & 7) * 4, srs = lane >> 3;
-  int s_off[4], s_nblk[4], s_nt4[4];  // per store i: the read's slot offset / blocks / owned slots (0: no such read)
+  int s_off[4], s_nblk[4], s_nt4[4];  // per i: the read's slot offset / blocks / owned slots (0: no such read)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rr = a.grp_reads[g * 32 + 8 * i + srs];
@@ -2108,38 +2074,39 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     s_nt4[i] = rr >= 0 ? (a.ntok[rr] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
   }
   float* const ychan = a.y + (int64_t)c * a.Tp;
-  float wq[2][20];
-  {
-    const int pp0 = p_out0 + wave;
-    const int64_t t00 = 32 * pp0 + eh;
-    load_win(t00, t00 > 0, pp0 <= p_out_last && pp0 < e_nblk, wq[0]);
-  }
+  const float* const x0chan = a.u + (int64_t)c * a.Tp;
+  // x0[t - 2 .. t + 3] of a lane's four tokens: the quad and the two values in front of it (TAB: token ids, expanded
+  // through the table at their use).  Requested one output block ahead of their use -- fetched when needed, each of the
+  // (up to) eight blocks of a wave paid a full memory round trip -- and branch-free: the block index is clamped into
+  // the read, results of clamped lanes are never stored.
+  struct XWin {
+    float4 cur;  // TAB: cur.x = four ids
+    float2 prv;  // TAB: prv.x = two ids
+  };
+  auto x_request = [&](int pp, XWin (&xw)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ppc = pp < s_nblk[i] ? pp : (s_nblk[i] > 0 ? s_nblk[i] - 1 : 0);
+      const int t = 32 * ppc + sq, tp = t >= 2 ? t - 2 : 0;
+      if (TAB) {
+        const unsigned char* tk = a.tok + s_off[i];
+        xw[i].cur = make_float4(__builtin_bit_cast(float, *reinterpret_cast<const uint32_t*>(tk + t)), 0.f, 0.f, 0.f);
+        xw[i].prv = make_float2(__builtin_bit_cast(float, (uint32_t)*reinterpret_cast<const unsigned short*>(tk + tp)), 0.f);
+      } else {
+        xw[i].cur = *reinterpret_cast<const float4*>(x0chan + s_off[i] + t);
+        xw[i].prv = *reinterpret_cast<const float2*>(x0chan + s_off[i] + tp);
+      }
+    }
+  };
+  XWin xq[2][4];
+  x_request(p_out0 + wave, xq[0]);
 #pragma unroll
   for (int m = 0; m < NACC; ++m) {
     const int pp = p_out0 + wave + 4 * m;
-    if (m + 1 < NACC) {
-      const int ppn = pp + 4;
-      const int64_t tn = 32 * ppn + eh;
-      load_win(tn, true, ppn <= p_out_last && ppn < e_nblk, wq[(m + 1) & 1]);
-    }
+    if (m + 1 < NACC) x_request(pp + 4, xq[(m + 1) & 1]);
     if (pp <= p_out_last) {  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * h) * PS + r32] = acc[m][e];
-      if (pp < e_nblk) {
-        float(&w)[20] = wq[m & 1];
-        expand_win(w);
-        float4* prow = reinterpret_cast<float4*>(patch + er * PS + eh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float4 v = prow[j];
-          const int s = 4 * j;
-          v.x *= inv_sc * fmaf(wx0_0, w[s + 2], fmaf(wx0_1, w[s + 3], fmaf(wx0_2, w[s + 4], bx0)));
-          v.y *= inv_sc * fmaf(wx0_0, w[s + 3], fmaf(wx0_1, w[s + 4], fmaf(wx0_2, w[s + 5], bx0)));
-          v.z *= inv_sc * fmaf(wx0_0, w[s + 4], fmaf(wx0_1, w[s + 5], fmaf(wx0_2, w[s + 6], bx0)));
-          v.w *= inv_sc * fmaf(wx0_0, w[s + 5], fmaf(wx0_1, w[s + 6], fmaf(wx0_2, w[s + 7], bx0)));
-          prow[j] = v;
-        }
-      }
       // (one wave: LDS operations are in order; the fence only pins the compiler)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2147,7 +2114,23 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (pp < s_nblk[i] && ts < s_nt4[i]) {
-          const float4 v = *reinterpret_cast<const float4*>(patch + (8 * i + srs) * PS + sq);
+          const XWin& xw = xq[m & 1][i];
+          float w[6];
+          if (TAB) {
+            const uint32_t ic = __builtin_bit_cast(uint32_t, xw.cur.x), ip = __builtin_bit_cast(uint32_t, xw.prv.x);
+            w[0] = tab_at(0, ip, 0);
+            w[1] = tab_at(0, ip, 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) w[2 + b] = tab_at(0, ic, b);
+          } else {
+            w[0] = xw.prv.x, w[1] = xw.prv.y, w[2] = xw.cur.x, w[3] = xw.cur.y, w[4] = xw.cur.z, w[5] = xw.cur.w;
+          }
+          if (ts == 0) w[0] = w[1] = 0.f;  // Conv1d padding in front of the read
+          float4 v = *reinterpret_cast<const float4*>(patch + (8 * i + srs) * PS + sq);
+          v.x = v.x * inv_sc * fmaf(wx0_0, w[0], fmaf(wx0_1, w[1], fmaf(wx0_2, w[2], bx0)));
+          v.y = v.y * inv_sc * fmaf(wx0_0, w[1], fmaf(wx0_1, w[2], fmaf(wx0_2, w[3], bx0)));
+          v.z = v.z * inv_sc * fmaf(wx0_0, w[2], fmaf(wx0_1, w[3], fmaf(wx0_2, w[4], bx0)));
+          v.w = v.w * inv_sc * fmaf(wx0_0, w[3], fmaf(wx0_1, w[4], fmaf(wx0_2, w[5], bx0)));
           *reinterpret_cast<float4*>(ychan + s_off[i] + ts) = v;
         }
       }
