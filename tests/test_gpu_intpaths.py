@@ -131,6 +131,37 @@ def test_tokenize_truncation_and_flags(env):
         np.testing.assert_array_equal(out["input_quals"].cpu().numpy()[r, max_length - n:], feats[k]["input_quals"])
 
 
+@pytest.mark.parametrize("qual_offset", [33, 64, 128, 129, 200])
+def test_tokenize_quality_offsets_and_underflow_flag(env, qual_offset):
+    """encode_qual with other offsets (src/python.rs:26: `q - offset` as u8): the word-wise "a byte is below the offset" test
+    holds for offsets <= 128 and hands over to a per-byte test above; shifting qualities and offset together must not change
+    one bit, and a single byte below the offset -- in the first, a middle or the last chunk of a read -- raises the flag of
+    that read only."""
+    torch, ops = env
+    rng = np.random.default_rng(qual_offset)
+    lens = [5, 16, 17, 100, 1000, 1023]
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [al[rng.integers(0, 4, n)].tobytes() for n in lens]
+    ph = [rng.integers(1, 41, n).astype(np.uint8) for n in lens]
+    sb, offs = ops.pack_reads(seqs)
+    stride = max(lens) + 1
+
+    def run(off, phreds):
+        qb, _ = ops.pack_reads([(p + off).astype(np.uint8).tobytes() for p in phreds])
+        out = ops.tokenize_batch(ops.to_device(sb), ops.to_device(qb), ops.to_device(offs), max_length=32769, row_stride=stride,
+                                 pad_left=True, ids_i64=False, qual_offset=off)
+        return out["input_quals"].cpu().numpy(), out["status"].cpu().numpy()
+
+    base_q, base_st = run(33, ph)
+    q, st = run(qual_offset, ph)
+    assert np.array_equal(q.view(np.uint32), base_q.view(np.uint32)) and np.all(st == 0) and np.all(base_st == 0)
+    for r, pos in ((3, 0), (4, 500), (5, 1022), (0, 4)):
+        bad = [p.astype(np.int64) for p in ph]
+        bad[r][pos] = -1  # one byte just below the offset
+        _, st = run(qual_offset, bad)
+        assert [bool(x & 4) for x in st] == [i == r for i in range(len(lens))], (r, pos, st)
+
+
 def test_tokenize_against_reference_fixture(env, golden_dir):
     """Real reads (decoded from the reference's .pt fixture): our kernel reproduces the
     reference's own input_ids / labels rows and its quality normalisation."""
@@ -333,7 +364,7 @@ def test_smooth_from_logits_reference_fixtures(env, golden_dir, name):
 
 
 @pytest.mark.parametrize("stride", [1001, 2048, 2049, 4096, 4097])
-@pytest.mark.parametrize("window", [1, 3, 21, 31, 33, 101])
+@pytest.mark.parametrize("window", [1, 2, 3, 21, 30, 31, 32, 33, 101])
 def test_smooth_from_logits_forms_and_windows(env, stride, window):
     """Every form of the logits-mode smoothing kernel (64 threads / 2 048 positions, 128 / 4 096, 256 / 65 536, chosen by
     row stride) with both window evaluations (32-bit register windows up to 31, word-prefix counts above), reads whose
