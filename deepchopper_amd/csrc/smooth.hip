@@ -90,6 +90,9 @@ __device__ __forceinline__ int run_start(const unsigned long long* words, int i)
   }
 }
 
+#ifndef SM_OCC64
+#define SM_OCC64 6  // waves per SIMD asked of the 64-thread form (79 VGPRs, no spill; the larger forms would spill)
+#endif
 #ifndef SM_S0_BATCH
 #define SM_S0_BATCH 4
 #endif
@@ -106,7 +109,7 @@ __device__ __forceinline__ uint4 bits_to_bytes16(unsigned m) {
 // is a wave-local no-op, 28 reads resident per CU; a capacity of 16 words made hipcc turn the single-trip chunk loops into
 // straight-line code with 197 VGPRs); the 256-thread form holds reads up to 65 536 bases.
 template <bool FROM_LOGITS, int BS, int CAPW>
-__global__ __launch_bounds__(BS) void smooth_kernel(SmoothArgs a) {
+__global__ __launch_bounds__(BS, BS == 64 ? SM_OCC64 : 1) void smooth_kernel(SmoothArgs a) {
   __shared__ unsigned long long s_raw[CAPW];   // raw labels, later "kept run end" flags
   __shared__ unsigned long long s_sm[CAPW];    // smoothed labels
   __shared__ unsigned s_pref[CAPW + 1];
