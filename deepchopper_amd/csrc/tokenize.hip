@@ -80,6 +80,9 @@ __global__ void encode_qual_kernel(const uint8_t* __restrict__ q, int64_t n, uin
 // and the partial chunk at the end of a row go through a byte-wise path.  Arithmetic is unchanged: exact integer sum
 // of squares -> sqrtf -> IEEE division per base.
 constexpr int TK_WAVES = 4;  // reads per 256-thread workgroup
+#ifndef TK_OCC
+#define TK_OCC 7  // waves per SIMD asked of the compiler (72 VGPRs, no spill; eight spill 48 bytes)
+#endif
 
 // bit b of a nibble -> byte b of a word = 0xFF
 __device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t n) {
@@ -88,7 +91,7 @@ __device__ __forceinline__ uint32_t nibble_to_bytes(uint32_t n) {
 }
 
 template <typename IdT>
-__global__ __launch_bounds__(64 * TK_WAVES) void tokenize_batch_kernel(
+__global__ __launch_bounds__(64 * TK_WAVES, TK_OCC) void tokenize_batch_kernel(
     const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const int64_t* __restrict__ offsets,
     int n_reads, int max_length, uint8_t qual_offset, int64_t row_stride, int pad_left,
     IdT* __restrict__ ids, float* __restrict__ quals, int8_t* __restrict__ labels,
