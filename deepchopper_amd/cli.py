@@ -167,32 +167,45 @@ def _merge_under_external_launcher(args, rank: int, world: int, parts: list[str]
 
     own = not dist.is_initialized()
     if own:  # gloo announces its connections on stdout, which carries the output path: point fd 1 at stderr meanwhile
+        import datetime
+
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("gloo")
+            # a rank that died in predict_chop never arrives: do not wait gloo's default 30 minutes for it under a launcher
+            # that leaves the siblings alone (srun, mpirun); bench.py bounds the same barrier pattern the same way
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
             dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    failure = None
     try:
         counts = [None] * world
         dist.all_gather_object(counts, (n_reads, n_records))
         if rank == 0:
-            tot_r, tot_o = sum(c[0] for c in counts), sum(c[1] for c in counts)
-            if tot_r == 0:
-                raise ValueError(f"No valid records found in {args.data_path}")
-            final = chop_mod._final_name(str(args.data_path), args.chop_output, tot_r, tot_o)
-            chop_mod.merge_bgzf_parts(parts, final, interleaved=interleaved)
-            print(final)
-        dist.barrier()
+            try:
+                tot_r, tot_o = sum(c[0] for c in counts), sum(c[1] for c in counts)
+                if tot_r == 0:
+                    raise ValueError(f"No valid records found in {args.data_path}")
+                final = chop_mod._final_name(str(args.data_path), args.chop_output, tot_r, tot_o)
+                chop_mod.merge_bgzf_parts(parts, final, interleaved=interleaved)
+                print(final)
+            except Exception as e:  # rank 0 must still reach the rendezvous below, or the others wait out the timeout
+                failure = e
+        verdict = [None if failure is None else f"{type(failure).__name__}: {failure}"]
+        dist.broadcast_object_list(verdict, src=0)  # doubles as the final barrier; every rank learns the outcome
+        if verdict[0] is not None and rank != 0:
+            failure = RuntimeError(f"rank 0 could not merge the per-rank outputs: {verdict[0]}")
     finally:
         if rank == 0:
             chop_mod.remove_parts(parts)
         if own:
             dist.destroy_process_group()
+    if failure is not None:
+        raise failure  # every rank exits non-zero
 
 
 def _predict(args, argv: list[str]) -> int:
@@ -200,6 +213,12 @@ def _predict(args, argv: list[str]) -> int:
     if not data_path.exists():
         print(f"Error: Data path '{data_path}' does not exist.", file=sys.stderr)
         return 1
+    if args.gpus is None:
+        # the reference's documented command is `deepchopper predict reads.fq` (default --gpus 0 = CPU, deepchopper/cli.py:66-90,
+        # 126-138).  This build has no CPU mode; the omitted flag means "one GPU" instead of an error.
+        args.gpus = 1
+        if os.environ.get("DC_SELF_LAUNCHED") != "1":
+            print("Note: no CPU mode in this build; using GPU 0 (pass --gpus N for N GPUs).", file=sys.stderr)
     if args.gpus < 1:
         print("Error: deepchopper_amd runs only on the GPU (use --gpus 1..8); there is no CPU fallback.", file=sys.stderr)
         return 1
@@ -328,7 +347,9 @@ def main(argv=None) -> int:
     sub = ap.add_subparsers(dest="cmd", required=True)
     p = sub.add_parser("predict", help="DeepChopper: predict the given dataset")
     p.add_argument("data_path", help="Path to the dataset")
-    p.add_argument("--gpus", "-g", type=int, default=0, help="Number of GPUs to use")
+    p.add_argument("--gpus", "-g", type=int, default=None,
+                   help="Number of GPUs to use (omitted: one GPU -- the reference's default 0 means CPU, which this build "
+                        "does not have; an explicit 0 is an error)")
     p.add_argument("--output", "-o", default=None, help="Output path for predictions")
     p.add_argument("--batch-size", "-b", type=int, default=12, help="Batch size")
     p.add_argument("--workers", "-w", type=int, default=0, help="Number of workers (unused: tokenisation runs on the GPU)")

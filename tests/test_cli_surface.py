@@ -30,7 +30,8 @@ def test_predict_flags_and_defaults():
         assert flag in h, flag
     import argparse
 
-    # defaults of the reference: -g 0, -b 12, -w 0, -m rna002 (cli.py:70-84)
+    # defaults of the reference: -b 12, -w 0, -m rna002 (cli.py:70-84).  Its `-g 0` (CPU) does not exist in this build: an
+    # omitted --gpus parses as None = "one GPU, with a notice" (test_default_invocation_takes_one_gpu_with_a_notice)
     ns = {}
     orig = argparse.ArgumentParser.parse_args
 
@@ -45,7 +46,7 @@ def test_predict_flags_and_defaults():
             cli.main(["predict", "reads.fq"])
     finally:
         argparse.ArgumentParser.parse_args = orig
-    assert (ns["gpus"], ns["batch_size"], ns["workers"], ns["model"], ns["output"]) == (0, 12, 0, "rna002", None)
+    assert (ns["gpus"], ns["batch_size"], ns["workers"], ns["model"], ns["output"]) == (None, 12, 0, "rna002", None)
     assert ns["limit_batches"] is None and ns["max_sample"] is None and ns["threads"] == 4  # --chop's measured default
 
 
@@ -85,6 +86,28 @@ def test_no_cpu_mode_is_said_out_loud(tmp_path, capsys):
     fq.write_text("@r\nACGT\n+\nIIII\n")
     assert cli.main(["predict", str(fq), "-g", "0"]) == 1
     assert "no CPU fallback" in capsys.readouterr().err
+
+
+def test_default_invocation_takes_one_gpu_with_a_notice(tmp_path, capsys, monkeypatch):
+    """`deepchopper predict reads.fq` -- the reference's documented command (deepchopper/cli.py:66-90: `--gpus` defaults to 0 =
+    CPU, :126-138) -- must not be an error here: the omitted flag means one GPU, said in one line on stderr.  (No GPU in
+    the CPU suite: the run is cut where the first HIP call would be made, behind the GPU-count gate.)"""
+    from deepchopper_amd import _lib
+
+    class Reached(Exception):
+        pass
+
+    def stop():
+        raise Reached
+
+    monkeypatch.setattr(_lib, "require_gpu", stop)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    fq = tmp_path / "r.fq"
+    fq.write_text("@r\nACGT\n+\nIIII\n")
+    with pytest.raises(Reached):
+        cli.main(["predict", str(fq)])
+    err = capsys.readouterr().err
+    assert "no CPU mode in this build; using GPU 0" in err and "Error" not in err
 
 
 def test_import_name_of_the_reference_resolves_to_this_package():

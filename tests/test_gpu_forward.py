@@ -148,6 +148,73 @@ def test_forward_deterministic_and_batch_invariant(env):
     np.testing.assert_allclose(c[0], a[3], rtol=0, atol=1e-5)
 
 
+CAUSAL_CASES = [  # (tokens per row, long-convolution path, stage that must have run, launches)
+    (600, "block-Toeplitz MFMA, one chunk", None, 0),
+    (1500, "block-Toeplitz MFMA, (output, input) chunk windows", None, 0),
+    (3000, "in-LDS radix-16 FFT", "hyena_fft", 4),
+    (20000, "four-step 2^15-point FFT", "hyena_fft15", 4),
+]
+
+
+@pytest.mark.parametrize("L,path,stage,launches", CAUSAL_CASES, ids=[str(c[0]) for c in CAUSAL_CASES])
+def test_forward_is_causal_and_pad_prefix_is_row_independent(env, L, path, stage, launches):
+    """The two properties HyenaDNA has and the model behind the reference's committed `.pt` fixtures has not
+    (tests/test_reference_fixture_model.py: BenchmarkCNN, receptive field +-12), on the HIP path, in every GEMM mode and on
+    every long-convolution path:
+
+    (i)  in a left-padded batch (deepchopper/models/llm/tokenizer.py:71-87) the logits over the [PAD] prefix two rows share
+         do not depend on the row -- all the way to the end of the shorter pad run: no look-ahead;
+    (ii) logits at positions <= t do not change when tokens / qualities at positions > t change (`short_filter(...)[..., :L]`
+         and the 2L-point `fftconv` of the reference's backbone, restated in oracle/forward_ref.py:68-77,106-113).
+
+    The block-Toeplitz MFMA kernel is exactly causal (its blocks above the diagonal are exactly zero), so both hold BIT FOR
+    BIT there.  The FFT forms compute what the reference's `fftconv` computes -- a circular convolution of the whole row
+    -- so later tokens reach earlier outputs as fp32 rounding noise (the reference has the same property); held to 5e-5,
+    20 times inside north_star's 1e-3."""
+    torch, ops, sd, model = env
+    rng = np.random.default_rng(L)
+    B = 4
+    ids, q = _inputs(rng, B, L)
+    npad = [L // 2, L // 5, (2 * L) // 3, 0]
+    for b, n in enumerate(npad):
+        ids[b, :n] = 4
+        q[b, :n] = 0
+    model.set_profiling(True)
+    model.profile_reset()
+    try:
+        a = model.forward(ops.to_device(ids.astype(np.uint8)), ops.to_device(q)).cpu().numpy()
+        stages = model.profile()
+    finally:
+        model.set_profiling(False)
+    assert np.isfinite(a).all()
+    if stage is not None:
+        assert stages.get(stage, (0, 0))[1] == launches, (path, stages)
+    else:
+        assert stages.get("hyena_fft", (0, 0))[1] == 0 and stages.get("hyena_fft15", (0, 0))[1] == 0, (path, stages)
+    exact = stage is None
+    tol = 0.0 if exact else 5e-5
+
+    def same(x, y, what):
+        if exact:
+            assert np.array_equal(x, y), f"{path}: {what}: max |d| = {np.abs(x - y).max():.3e} (must be bit-identical)"
+        else:
+            assert np.abs(x - y).max() <= tol, f"{path}: {what}: max |d| = {np.abs(x - y).max():.3e} > {tol}"
+
+    # (i) shared pad prefix, every pair of padded rows
+    for r in range(3):
+        for s in range(r + 1, 3):
+            m = min(npad[r], npad[s])
+            same(a[r, :m], a[s, :m], f"pad prefix of rows {r},{s} (first {m} positions)")
+    # (ii) change everything behind t: the bases, the qualities, and (row 1) the amount of padding that follows
+    t = L // 3
+    ids2, q2 = ids.copy(), q.copy()
+    ids2[:, t + 1: L - 1] = rng.integers(7, 12, (B, L - t - 2))
+    q2[:, t + 1:] = rng.random((B, L - t - 1)).astype(np.float32)
+    b2 = model.forward(ops.to_device(ids2.astype(np.uint8)), ops.to_device(q2)).cpu().numpy()
+    same(a[:, : t + 1], b2[:, : t + 1], f"logits at positions <= {t} after changing positions > {t}")
+    assert np.abs(a[:, t + 1:] - b2[:, t + 1:]).max() > 1e-3  # ... and the change did reach the positions behind t
+
+
 def test_forward_at_bench_shape_properties(env):
     """1 kb reads at a bench-like batch: finite, deterministic, spot-checked against the oracle."""
     torch, ops, sd, model = env

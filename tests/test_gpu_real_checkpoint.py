@@ -1,13 +1,22 @@
 """The F2 pin harness (GPU side).
 
+What pins the HyenaDNA backbone, and what does not, is spelled out in tests/real_ckpt.py.  In short: the reference's
+committed tests/data/eval/*.pt are `BenchmarkCNN` outputs (tests/test_reference_fixture_model.py), so the replay takes the
+reference's OWN `deepchopper predict` output with the real model from $DEEPCHOPPER_REF_PT_DIR instead.
+
 1. Always runs: a checkpoint saved exactly the way the reference's `PyTorchModelHubMixin` saves it
    (`safetensors.torch.save_model`: shared `Sin` aliases dropped) loads through `DeepChopper.from_pretrained` and gives
    bit-identical logits to the same weights handed over as a plain state dict.
-2. Skipped unless $DEEPCHOPPER_MODEL_DIR holds the real weights: the reference's own 72 stored-logit reads
-   (/root/reference/tests/data/eval/chunk{0,1}/{0,1,2}.pt, committed as tests/golden/eval_chunk*.npz) are replayed through
-   `dc_forward` with the rows left-padded exactly as stored, in all three GEMM modes: max |dlogit| <= 1e-3 against the
-   stored `prediction`, labels / smoothed labels / intervals identical.  This is the only test that can pin the
-   third-party HyenaDNA backbone; the CPU oracle's twin is tests/test_oracle_real_checkpoint.py."""
+2. Always runs: the replay's own code path on `.pt` files in the `CustomWriter` format written into a temporary directory --
+   synthetic weights in the role of the real ones, the oracle's logits for those weights in the role of the reference's
+   output -- and its refusal of a `.pt` that shows look-ahead (the reference's CNN fixture, re-written as a `.pt`).
+3. Skipped unless $DEEPCHOPPER_REF_PT_DIR (+ $DEEPCHOPPER_MODEL_DIR) is given: every `{rank}_{batch}.pt` the reference's
+   `deepchopper predict` wrote (deepchopper/models/callbacks.py:12-25) is replayed through `dc_forward`, rows left-padded
+   exactly as stored, in all three GEMM modes: max |dlogit| <= 1e-3 against the stored `prediction`, labels / smoothed
+   labels / intervals identical.  This is the only test that can pin the third-party backbone; the CPU oracle's
+   twin is tests/test_oracle_real_checkpoint.py.
+4. Skipped unless $DEEPCHOPPER_MODEL_DIR is given (weights, but no reference output): HIP against the CPU oracle on the
+   trained weights -- fp16x3 range guard and tolerance on a real checkpoint; pins the kernels, not the restatement."""
 import os
 
 import numpy as np
@@ -42,7 +51,7 @@ def test_from_pretrained_with_mixin_style_checkpoint_equals_plain_state_dict(hip
     assert np.isfinite(la).all() and np.array_equal(la, lb)
 
 
-def _replay(model, batch, want, tag):
+def _replay(model, batch, want, tag, tol=real_ckpt.TOL_LOGIT):
     """Rows exactly as stored (left pad runs through the model) -> dc_forward in the three GEMM modes -> S0..S3 on the
     GPU, against `want` logits and the oracle's labels / smoothed labels / intervals computed from `want`."""
     from deepchopper_amd import ops
@@ -59,11 +68,11 @@ def _replay(model, batch, want, tag):
     n_checked = 0
     for mode in ("f32", "bf16x6", "fp16x3"):
         model.net.set_gemm_mode(mode)
-        logits = model.net.forward(d_ids, d_q)
+        logits = model.net.forward_checked(d_ids, d_q)  # fp16x3: range guard + bf16x6 redo, as `predict` runs it
         got = logits.cpu().numpy()
         assert np.isfinite(got).all()
         err = float(np.abs(got - want).max())
-        assert err <= real_ckpt.TOL_LOGIT, f"{tag} [{mode}]: max |dlogit| = {err:.3e}"
+        assert err <= tol, f"{tag} [{mode}]: max |dlogit| = {err:.3e}"
         out = ops.smooth_intervals_from_logits(logits, ops.to_device(first), ops.to_device(length), window=21,
                                                min_interval=13, approved=20)
         offs = out["offsets"].cpu().numpy()
@@ -73,7 +82,7 @@ def _replay(model, batch, want, tag):
             rid = "".join(chr(c) for c in idm[b, 2: 2 + idm[b, 0]])
             p = preds[rid]
             mine = pred[offs[b]: offs[b + 1]]
-            near_tie = margin[b, first[b]: first[b] + length[b]] < 2 * real_ckpt.TOL_LOGIT
+            near_tie = margin[b, first[b]: first[b] + length[b]] < 2 * tol
             assert np.array_equal(mine[~near_tie], p.prediction[~near_tie]), f"{tag} [{mode}] read {rid}: labels differ"
             if np.array_equal(mine, p.prediction):  # (a label inside the logit tolerance may legitimately flip)
                 assert np.array_equal(sm[offs[b]: offs[b + 1]], p.smooth_label(21))
@@ -83,10 +92,32 @@ def _replay(model, batch, want, tag):
     return n_checked
 
 
+def replay_reference_output(model, files):
+    """The pin itself: every `CustomWriter` file, refused if its writer was not causal, replayed as stored."""
+    n = 0
+    for path in files:
+        batch = real_ckpt.load_reference_pt(path)
+        real_ckpt.require_causal(batch, os.path.basename(path))
+        n += _replay(model, batch, batch["prediction"].astype(np.float32), os.path.basename(path))
+    return n
+
+
+def _write_custom_writer_pt(path, batch, prediction):
+    """A file in the reference's wire format (callbacks.py:17-25) from a numpy batch."""
+    import torch
+
+    torch.save({"prediction": torch.from_numpy(np.ascontiguousarray(prediction, dtype=np.float32)),
+                "target": torch.from_numpy(batch["target"].astype(np.int64)),
+                "seq": torch.from_numpy(batch["seq"].astype(np.int64)),
+                "qual": torch.from_numpy(batch["qual"].astype(np.float32)),
+                "id": torch.from_numpy(batch["id"].astype(np.int64))}, path)
+
+
 def test_replay_harness_mechanics_with_a_synthetic_checkpoint(hip_lib, golden_dir, tmp_path):
-    """The replay below is skipped without real weights; its code path is exercised here on every GPU run: synthetic
-    weights saved the mixin's way, the fixture's real rows (left pad, SEP, quality row, id row) as input, and the CPU
-    oracle's logits for THOSE weights in the role of the stored `prediction`."""
+    """The replay of item 3 is skipped without the reference's output; its code path -- directory of `.pt` files in,
+    causality gate, three GEMM modes, labels / smoothed labels / intervals -- runs here on every GPU pass: synthetic
+    weights saved the mixin's way, the reference fixture's real rows (left pad, SEP, quality row, id row) as input, and
+    the CPU oracle's logits for THOSE weights in the role of the stored `prediction`."""
     from safetensors.torch import save_model
 
     from deepchopper_amd.model import DeepChopper
@@ -101,15 +132,43 @@ def test_replay_harness_mechanics_with_a_synthetic_checkpoint(hip_lib, golden_di
     rows, cols = slice(0, 4), slice(-900, None)  # the last 900 columns: pad + read for some rows, all read for others
     batch = {k: (d[k][rows, cols] if k not in ("id",) else d[k][rows]) for k in d.files if k != "prediction"}
     want = fr.forward(sd, batch["seq"].astype(np.int64), batch["qual"].astype(np.float32)).numpy()
-    assert _replay(model, batch, want, "synthetic") > 0
+    out = tmp_path / "predictions" / "0"
+    out.mkdir(parents=True)
+    _write_custom_writer_pt(str(out / "0_0.pt"), batch, want)
+    files = [str(out / "0_0.pt")]
+    assert replay_reference_output(model, files) > 0
+    # the reference's committed fixture in the same format: written by BenchmarkCNN -> refused, whatever the weights
+    cnn = {k: d[k] for k in d.files}
+    _write_custom_writer_pt(str(out / "0_1.pt"), cnn, cnn["prediction"])
+    with pytest.raises(AssertionError, match="looks ahead"):
+        replay_reference_output(model, [str(out / "0_1.pt")])
 
 
-@pytest.mark.skipif(real_ckpt.find_real_checkpoint() is None, reason=real_ckpt.SKIP_REASON)
-@pytest.mark.parametrize("name", real_ckpt.fixture_names())
-def test_real_checkpoint_replays_reference_fixtures(hip_lib, golden_dir, name):
+@pytest.mark.skipif(not real_ckpt.find_reference_pt_files() or real_ckpt.find_real_checkpoint() is None,
+                    reason=real_ckpt.SKIP_NO_REF_OUTPUT)
+def test_real_checkpoint_replays_reference_output(hip_lib):
     from deepchopper_amd.model import DeepChopper
 
     model = DeepChopper.from_pretrained(real_ckpt.find_real_checkpoint())
+    assert replay_reference_output(model, real_ckpt.find_reference_pt_files()) > 0
+
+
+@pytest.mark.skipif(real_ckpt.find_real_checkpoint() is None, reason=real_ckpt.SKIP_NO_CKPT)
+@pytest.mark.parametrize("name", real_ckpt.fixture_names()[:2])
+def test_real_checkpoint_hip_vs_oracle_on_reference_reads(hip_lib, golden_dir, name):
+    """Weights but no reference output: HIP vs the CPU oracle on the TRAINED weights, on the real reads of the reference's
+    fixtures (inputs only -- their stored logits belong to another model).  Exercises the fp16x3 range guard and the
+    1e-3 tolerance on a trained checkpoint; it pins the kernels against the restatement, not the restatement."""
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.weights import load_checkpoint
+    from oracle import forward_ref as fr
+
+    ck = real_ckpt.find_real_checkpoint()
+    sd, cfg = load_checkpoint(ck)
+    model = DeepChopper.from_pretrained(ck)
     d = np.load(os.path.join(golden_dir, name))
-    batch = {k: d[k] for k in d.files}
-    _replay(model, batch, batch["prediction"], name)
+    rows = slice(0, 4)  # minutes on the CPU side otherwise
+    batch = {k: d[k][rows] for k in d.files if k != "prediction"}
+    ocfg = fr.HyenaDNAConfig(**{k: v for k, v in cfg.to_dict().items() if k in fr.HyenaDNAConfig.__dataclass_fields__})
+    want = fr.forward(sd, batch["seq"].astype(np.int64), batch["qual"].astype(np.float32), ocfg).numpy()
+    assert _replay(model, batch, want, f"{name} (oracle on real weights)") >= 0

@@ -55,3 +55,72 @@ def test_single_process_helpers_are_identity():
     assert dist_max(3.5) == 3.5
     dist_barrier()
     assert gather_results({"a": 1}) == {"a": 1}
+
+
+def _merge_rank(rank, world, port, fq_path, parts, sabotage, out_dir):
+    """A rank of `predict --chop` under an external launcher, after its predict_chop: parts written, counts known."""
+    import argparse
+    import json
+
+    from deepchopper_amd import cli
+
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    args = argparse.Namespace(data_path=fq_path, chop_output=os.path.join(out_dir, "merged"))
+    outcome = "ok"
+    try:
+        counts = (0, 0) if sabotage else ((3, 3) if rank == 0 else (2, 2))
+        cli._merge_under_external_launcher(args, rank, world, parts, counts[0], counts[1], interleaved=False)
+    except Exception as e:
+        outcome = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out_dir, f"outcome{rank}.json"), "w") as fh:
+        json.dump(outcome, fh)
+
+
+def _make_parts(tmp_path):
+    from deepchopper_amd.chop import write_part_index
+    from deepchopper_amd.fastq import BgzfWriter, FastqChunk, FastqReader
+
+    def copy(c):  # a reader's chunks share its staging buffers
+        return FastqChunk(c.n, c.seq.copy(), c.qual.copy(), c.offsets.copy(), c._names.copy(), c._name_offsets.copy(),
+                          None if c._name_len is None else c._name_len.copy())
+
+    seqs, quals, ids = synth.synth_reads_mixed(5, 60, 200, seed=4)
+    text = synth.to_fastq(seqs, quals, ids)
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(text)
+    parts = []
+    with FastqReader(str(fq)) as rd:
+        chunks = [copy(c) for c in rd.chunks(1, 1 << 20)]
+        for r, sl in enumerate((slice(0, 3), slice(3, 5))):
+            parts.append(str(tmp_path / f"part.rank{r}"))
+            w = BgzfWriter(parts[-1], threads=1)
+            with w:
+                for c in chunks[sl]:
+                    w.write_chunk(c)
+                    w.mark()
+            write_part_index(parts[-1], w)
+    return str(fq), parts, text
+
+
+def test_external_launcher_merge_and_failure_reaches_every_rank(tmp_path):
+    """`predict --chop` under torch.distributed.run (cli._merge_under_external_launcher): rank 0 splices the parts; when its
+    merge fails, EVERY rank learns it at the rendezvous and raises -- nobody waits out a timeout, nothing is left behind
+    (rank 0 used to raise before the final barrier)."""
+    import glob
+    import gzip
+    import json
+
+    for sabotage in (False, True):
+        d = tmp_path / f"case{int(sabotage)}"
+        d.mkdir()
+        fq, parts, text = _make_parts(d)
+        mp.spawn(_merge_rank, args=(2, _free_port(), fq, parts, sabotage, str(d)), nprocs=2, join=True)
+        outcomes = [json.load(open(d / f"outcome{r}.json")) for r in range(2)]
+        assert not any(os.path.exists(p) or os.path.exists(p + ".idx.npy") for p in parts)
+        merged = glob.glob(str(d / "merged*"))
+        if sabotage:
+            assert "No valid records" in outcomes[0] and "rank 0 could not merge" in outcomes[1], outcomes
+            assert merged == []
+        else:
+            assert outcomes == ["ok", "ok"], outcomes
+            assert len(merged) == 1 and gzip.open(merged[0], "rb").read() == text
