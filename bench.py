@@ -95,27 +95,111 @@ def cpu_baseline(seqs, quals, ids, sd, budget_s: float):
 
     # The thread count is part of the baseline: torch's default (every host core, 128 on the GPU box) is NOT the fastest
     # setting for batches of 12 x 1 001 tokens (round 2 reported 7.3 reads/s on 128 threads, slower than the reference's
-    # own prose figure).  Probe 8 / 16 / 32 / all on one reference batch each and measure with the best.
+    # own prose figure).  Probe 4 / 8 / 16 / ... on one reference batch each and measure with the best.
     ncpu = os.cpu_count() or 1
-    res = run(range(12))  # warm-up: first-touch allocations, filter materialisation in the oracle
+    t_w = time.perf_counter()
+    res = run(range(min(12, len(seqs))))  # warm-up: first-touch allocations, filter materialisation in the oracle
+    spent = time.perf_counter() - t_w
     probe = {}
     for t in [x for x in (4, 8, 16, 32, 64, 128) if x <= ncpu] or [ncpu]:
+        if probe and spent > budget_s:
+            break  # a small --cpu-seconds must not be overrun by the probe itself
         torch.set_num_threads(t)
         t0 = time.perf_counter()
-        run(range(12))
-        probe[t] = round(12 / (time.perf_counter() - t0), 3)
+        run(range(min(12, len(seqs))))
+        dt = time.perf_counter() - t0
+        spent += dt
+        probe[t] = round(min(12, len(seqs)) / dt, 3)
         if probe[t] < 0.7 * max(probe.values()):
             break  # past the optimum: more threads only add synchronisation (all 256 host threads: 0.5 reads/s)
     best = max(probe, key=probe.get)
     torch.set_num_threads(best)
     per12 = 12 / probe[best]
-    spent = sum(12 / v for v in probe.values())
-    n_more = int(max(12, min(len(seqs) - 12, (budget_s - spent) / max(per12, 1e-3) * 12)) // 12 * 12)
-    n_more = min(n_more, (len(seqs) - 12) // 12 * 12)
+    n_more = int(max(0.0, (budget_s - spent) / max(per12, 1e-3)) * 12) // 12 * 12
+    n_more = max(0, min(n_more, (len(seqs) - 12) // 12 * 12))
+    if n_more == 0:  # fewer than 24 reads sampled, or the budget went into warm-up + probe: the probe's best IS the measurement
+        return probe[best], min(12, len(seqs)), best, res, probe
     t1 = time.perf_counter()
     res.update(run(range(12, 12 + n_more)))
     total = time.perf_counter() - t1
     return n_more / total, 12 + n_more, best, res, probe
+
+
+def _cpu_all_cores_worker(idx: int, n_proc: int, threads: int, cpus, read_len: int, budget_s: float, conn) -> None:
+    """One of the read-sharded oracle processes of the all-core CPU baseline (never touches the GPU)."""
+    if cpus and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import torch
+
+    torch.set_num_threads(threads)
+    sys.path.insert(0, ROOT)
+    from deepchopper_amd import synth
+    from deepchopper_amd.weights import synthetic_state_dict
+    from tools import bench_legs
+
+    sd = synthetic_state_dict(0)
+    seq, qual, ids = synth.synth_reads_fixed(600, read_len, seed=42, start_index=10_000 * (idx + 1))  # this process's shard
+    seqs, quals = [seq[i].tobytes() for i in range(600)], [qual[i].tobytes() for i in range(600)]
+    bench_legs.oracle_reads(sd, ids[:12], seqs[:12], quals[:12])  # warm-up
+    conn.send("ready")
+    conn.recv()  # all processes start their timed region together
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < budget_s and done + 12 <= 600:
+        bench_legs.oracle_reads(sd, ids[done: done + 12], seqs[done: done + 12], quals[done: done + 12])
+        done += 12
+    conn.send((done, time.perf_counter() - t0))
+    conn.close()
+
+
+def cpu_baseline_all_cores(best_threads: int, read_len: int, budget_s: float):
+    """`usable CPUs // best_threads` oracle processes, read-sharded (each on its own slice of the CPUs), timed together: the
+    figure that uses the host the way `north_star` words it ("the same box's host cores, core count stated").  Usable =
+    the affinity mask capped by the cgroup CPU quota (a GPU box hands a job a share of the host's 256 hardware threads)."""
+    import multiprocessing as mp
+
+    from deepchopper_amd import placement
+
+    usable = placement.usable_cpu_count()
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    n_proc = max(1, usable // best_threads)
+    layout = {"processes": n_proc, "threads_per_process": best_threads, "usable_cpus": usable, "affinity_cpus": len(allowed),
+              "cgroup_cpu_quota": placement.cpu_quota()}
+    if n_proc == 1:
+        return None, layout
+    ctx = mp.get_context("spawn")  # fresh interpreters: nothing that has initialised the GPU is forked
+    procs, conns = [], []
+    pin = len(allowed) >= n_proc * best_threads and placement.cpu_quota() is None
+    for i in range(n_proc):
+        a, b = ctx.Pipe()
+        cpus = allowed[i * best_threads: (i + 1) * best_threads] if pin else None
+        p = ctx.Process(target=_cpu_all_cores_worker, args=(i, n_proc, best_threads, cpus, read_len, budget_s, b), daemon=True)
+        p.start()
+        procs.append(p)
+        conns.append(a)
+    try:
+        for c in conns:
+            if not c.poll(180):
+                raise TimeoutError("an oracle process did not get ready")
+            c.recv()
+        for c in conns:
+            c.send("go")
+        results = []
+        for c in conns:
+            if not c.poll(budget_s * 4 + 120):
+                raise TimeoutError("an oracle process did not finish")
+            results.append(c.recv())
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+    layout["pinned_slices"] = bool(pin)
+    return sum(r[0] for r in results) / max(r[1] for r in results), layout
 
 
 def self_launch(args) -> None:
@@ -133,46 +217,6 @@ def self_launch(args) -> None:
     print(json.dumps(line))
 
 
-def file_e2e_leg(pipe, n_reads: int, read_len: int, batch: int) -> dict:
-    """FASTQ-inclusive rate (SURVEY 8d's metric is "FASTQ bytes in -> labels + intervals out"): `n_reads` synthetic
-    reads written to a FASTQ file, then file -> native reader -> pinned staging -> H2D -> tokenise / forward /
-    smooth -> D2H of labels + intervals through `predict_stream`.  An extra key of the bench line, not `value`."""
-    import tempfile
-
-    import torch
-
-    from deepchopper_amd import synth
-    from deepchopper_amd.fastq import FastqReader
-
-    tmp = tempfile.mkdtemp(prefix="dc_bench_")
-    path = os.path.join(tmp, "reads.fq")
-    with open(path, "wb") as fh:
-        for b0 in range(0, n_reads, 10_000):
-            n = min(10_000, n_reads - b0)
-            seq, qual, ids = synth.synth_reads_fixed(n, read_len, seed=42 + b0, start_index=b0)
-            fh.write(synth.to_fastq(seq, qual, ids))
-    try:
-        cap = batch * (read_len + 1)
-        with FastqReader(path) as rd:  # warm-up: pinned staging, copy stream
-            for i, _ in enumerate(pipe.predict_stream(rd.chunks(batch, cap))):
-                if i >= 1:
-                    break
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = n_iv = 0
-        with FastqReader(path) as rd:
-            for res in pipe.predict_stream(rd.chunks(batch, cap)):
-                n += len(res["names"])
-                n_iv += int(res["n_intervals"].sum())
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    finally:
-        os.remove(path)
-        os.rmdir(tmp)
-    return {"value": round(n / dt, 1), "unit": "reads/s", "reads": n, "seconds": round(dt, 3), "container": "plain FASTQ",
-            "what": "file -> parse -> H2D -> tokenise/forward/smooth -> D2H labels + intervals (predict_stream)"}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,13 +230,22 @@ def main():
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "fp16x3"], default=os.environ.get("DC_GEMM_MODE", "fp16x3"))
     ap.add_argument("--strict-steps", type=int, default=5, help="extra untimed-in-`value` leg in the strict fp32-equivalent "
                     "mode (bf16x6) -> `value_bf16x6` (0 = skip)")
-    ap.add_argument("--e2e-reads", type=int, default=100_000, help="FASTQ-inclusive leg through predict_stream -> `file_e2e` "
-                    "(N = 1 only; 0 = skip)")
+    ap.add_argument("--e2e-reads", type=int, default=1_000_000, help="FASTQ-inclusive leg through predict_stream -> `file_e2e`: "
+                    "configs[1]'s stated size, ~31 s sustained (N = 1 only; 0 = skip)")
+    ap.add_argument("--legs", default="c1,c3,c4,c5", help="per-config legs -> `configs.*` (N = 1 only; '' = none): c1 = 512 bp, "
+                    "c3 = 2 kb one-GPU slice, c4 = mixed 100 bp - 10 kb file, c5 = .fastq.gz -> chopped BGZF")
+    ap.add_argument("--c4-reads", type=int, default=40_000)
+    ap.add_argument("--c5-reads", type=int, default=300_000)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)  # parent: starts one worker per GPU before anything here touches the GPU
 
+    from deepchopper_amd import placement
+
+    # N > 1: a disjoint slice of its GPU's NUMA node's CPUs per rank -- before torch is imported and the GPU is touched, so
+    # that helper threads inherit it and pinned staging is allocated after binding (deepchopper_amd/placement.py)
+    placed = placement.apply_for_this_rank()
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,11 +331,13 @@ def main():
     prof = model.net.profile() if not args.no_profile else {}
     model.net.set_profiling(False)
     per_rank_s = [elapsed]
+    cpusets = [placed and placed["cpuset"]]
     if world > 1:
         own = time.perf_counter() - t0  # not comparable across ranks to better than the barrier; informational
         gathered = [None] * world
-        dist.all_gather_object(gathered, round(own, 6))
-        per_rank_s = gathered
+        dist.all_gather_object(gathered, (round(own, 6), placed and placed["cpuset"]))
+        per_rank_s = [g[0] for g in gathered]
+        cpusets = [g[1] for g in gathered]
 
     # strict fp32-equivalent arithmetic (error-free 3-way bf16 split), same config, a few steps: so that the
     # driver's record also carries the throughput of the mode that needs no range guard
@@ -352,9 +407,16 @@ def main():
             seqs = [seq[i].tobytes() for i in range(n_s)]
             quals = [qual[i].tobytes() for i in range(n_s)]
             rate, n_done, cores, ref, probe = cpu_baseline(seqs, quals, ids[:n_s], sd, args.cpu_seconds)
+            try:
+                all_rate, layout = cpu_baseline_all_cores(cores, L, args.cpu_seconds)
+            except Exception as e:  # a baseline leg must never take the bench line down with it
+                all_rate, layout = None, {"error": f"{type(e).__name__}: {e}"}
             cpu = {"value": round(rate, 3), "unit": "reads/s", "cores": cores, "kind": "port",
-                   "sample": f"{n_done - 12} of the same synthetic {L}-bp reads (after a 12-read warm-up and the thread probe), "
-                             f"oracle tokenise+forward(torch fp32, batch 12)+smooth",
+                   "sample": f"{max(n_done - 12, n_done if n_done <= 12 else 0)} of the same synthetic {L}-bp reads (after a 12-read "
+                             f"warm-up and the thread probe), oracle tokenise+forward(torch fp32, batch 12)+smooth",
+                   # the same oracle, read-sharded over every CPU this job may use (processes x threads below); None when
+                   # that is one process, i.e. `value` already uses them all.  A baseline, never credit.
+                   "value_all_cores": None if all_rate is None else round(all_rate, 3), "all_cores_layout": layout,
                    "thread_probe_reads_per_s": {str(k): v for k, v in probe.items()}, "host_cores": os.cpu_count(),
                    "reference_prose_cpu_reads_per_s": [46, 139],  # docs/faq.md:78-80 (2-6 h per 1 M reads), context only
                    "note": "CPU restatement (oracle/), not the reference binary: its backbone cannot be loaded here (SURVEY 8c)"}
@@ -378,8 +440,26 @@ def main():
                   "intervals_identical": bool(same_iv)}
 
         e2e = None
-        if world == 1 and args.e2e_reads > 0:
-            e2e = file_e2e_leg(pipe, args.e2e_reads, L, B)
+        configs = {}
+        if world == 1:
+            from tools import bench_legs
+
+            legs = [x for x in args.legs.split(",") if x]
+            if args.e2e_reads > 0:
+                e2e = bench_legs.file_e2e_leg(pipe, sd, args.e2e_reads, L, B)
+            if "c1" in legs:
+                configs["c1_512bp"] = bench_legs.resident_leg(
+                    pipe, sd, 1000, 512, 40, "configs[0]: 1 000 synthetic 512-bp reads = one step (the whole config), HBM-resident")
+                configs["c1_512bp"]["batch_4096"] = bench_legs.resident_leg(
+                    pipe, sd, 4096, 512, 10, "512-bp reads in batches of 4 096 (the shape's best batch)", check_reads=0)
+            if "c3" in legs:
+                configs["c3_2kb_1gpu_slice"] = bench_legs.resident_leg(
+                    pipe, sd, 1024, 2000, 12, "configs[2]: synthetic 2 kb reads, ONE GPU's slice of the read-sharded run "
+                                                "(1 024 reads per step; 8 ranks run 8 of these with no exchange), HBM-resident")
+            if "c4" in legs:
+                configs["c4_mixed"] = bench_legs.mixed_leg(pipe, sd, args.c4_reads)
+            if "c5" in legs:
+                configs["c5_gz_chop"] = bench_legs.gz_chop_leg(args.c5_reads, threads=4)
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",
@@ -404,7 +484,9 @@ def main():
             "value_bf16x6": strict["value"] if strict else None,
             "bf16x6_leg": strict,
             "file_e2e": e2e,
+            "configs": configs or None,
             "per_rank_seconds": per_rank_s,
+            "per_rank_cpuset": cpusets,
             "cpu_baseline": cpu,
             "parity": f1,
             "fp16_overflow_events": fp16_overflow,

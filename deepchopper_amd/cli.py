@@ -118,15 +118,17 @@ def _launch_workers(args, argv: list[str]) -> int:
     import subprocess
 
     parts = [f"{part_base}.rank{r}" for r in range(world)] if part_base else []
+    plan = launcher.cpu_plan(world, share)  # a disjoint CPU slice of its GPU's NUMA node per worker, the rest for this parent
     try:
         for r in range(world):
-            env = launcher.rank_env(r, world, port, share)
+            env = launcher.rank_env(r, world, port, share, plan)
             cmd = list(child)
             if feeder is not None:
                 cmd += ["--chunk-fd", str(feeder.read_fds[r])]
             if part_base:
                 cmd += ["--part-path", parts[r]]
             procs.append(subprocess.Popen(cmd, env=env, pass_fds=per_rank_fds[r] if per_rank_fds else (), stdout=subprocess.PIPE, text=True))
+        parent_cpus = launcher.bind_parent(plan)  # after the spawn (children must not inherit it), before the inflater threads
         if feeder is not None:
             feeder.start()
         outs = launcher.wait_ranks(procs)
@@ -137,7 +139,8 @@ def _launch_workers(args, argv: list[str]) -> int:
         if n_reads == 0:
             raise ValueError(f"No valid records found in {path}")
         summary = {"gpus": world, "reads": n_reads, "batches": sum(r["batches"] for r in reports),
-                   "per_rank_reads": [r["reads"] for r in reports]}
+                   "per_rank_reads": [r["reads"] for r in reports],
+                   "cpusets": {"parent": parent_cpus and parent_cpus["cpuset"], "ranks": [r.get("cpuset") for r in reports]}}
         if args.chop:
             n_out = sum(r["records"] for r in reports)
             final = chop_mod._final_name(path, args.chop_output, n_reads, n_out)
@@ -231,6 +234,9 @@ def _predict(args, argv: list[str]) -> int:
     import time
 
     t_start = time.time()
+    from . import placement
+
+    placed = placement.apply_for_this_rank()  # before torch is imported and before the first HIP call (pinned staging after binding)
     import torch
 
     from . import _lib
@@ -306,6 +312,8 @@ def _predict(args, argv: list[str]) -> int:
         raise ValueError(f"No valid records found in {data_path}")
     logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
     report = {"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records, **_process_accounting(t_start)}
+    if placed is not None:
+        report.update({"cpuset": placed["cpuset"], "numa_node": placed["numa_node"], "torch_threads": torch.get_num_threads()})
     if pipe_src is not None:
         report.update({"pipe_read_cpu_s": round(pipe_src.cpu_s, 3), "pipe_bytes": pipe_src.bytes})
     if args.chop:

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -41,6 +42,23 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE and one process may drive several, so a process-wide
+// "done" flag is wrong -- and a driver call per launch is host time on a path that is host-bound for small batches.
+// One bit per device and call site (a `static std::atomic<uint64_t>` inside the launch function template): the attribute
+// is set BEFORE the bit, so a thread that sees the bit may launch; two threads racing on a fresh device both set it.
+#define DC_SET_MAX_SMEM_ONCE_PER_DEVICE(kernel_ptr, bytes)                                                   \
+  do {                                                                                                       \
+    static std::atomic<uint64_t> _seen{0};                                                                   \
+    int _dev = -1;                                                                                           \
+    DC_HIP_CHECK(hipGetDevice(&_dev));                                                                       \
+    const uint64_t _bit = (_dev >= 0 && _dev < 64) ? (1ull << _dev) : 0;                                     \
+    if (!_bit || !(_seen.load(std::memory_order_acquire) & _bit)) {                                          \
+      DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)));           \
+      _seen.fetch_or(_bit, std::memory_order_release);                                                       \
+    }                                                                                                        \
+  } while (0)
 
 constexpr int WAVE = 64;
 

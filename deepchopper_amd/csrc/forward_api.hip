@@ -239,12 +239,16 @@ void fold_transpose(const float* W, const float* b, const float* gamma, const fl
   }
 }
 
-int ensure(DevBuf& b, size_t bytes) {
+int ensure(DevBuf& b, size_t bytes, bool zero_fill = true) {
   if (b.bytes >= bytes) return DC_OK;
   if (b.p) DC_HIP_CHECK(hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
   DC_HIP_CHECK(hipMalloc(&b.p, bytes));
+  if (!zero_fill) {  // a buffer that is written in full before it is read (the 2^15-point FFT's scratch)
+    b.bytes = bytes;
+    return DC_OK;
+  }
   // Token slots that belong to no read (the tail up to the 256-token tile) are computed but never meaningful;
   // the long-convolution kernel does not write them.  Starting from zeros keeps them finite for good, so they
   // can neither trip the fp16 range guard nor feed NaNs into the LayerNorm statistics of their tile.
@@ -635,12 +639,16 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   if ((rc = ensure_filters(m, st, taps_needed))) return rc;
   for (int b = 0; b < 6; ++b)
     if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
-  constexpr int kFft15Batch = 16;  // reads per launch pair of the 2^15 form: 64 MiB of scratch each
+  // reads per launch pair of the 2^15 form.  The scratch is D x 2^15 complex = 64 MiB per read and stays with the handle, so
+  // the batch is what bounds a handle's footprint: 4 reads = 256 MiB at most (16 would hold 1 GiB for good, per handle --
+  // lanes, or ranks sharing a GPU), and a launch of 4 reads is already 8 x 4 x 256 = 8 192 workgroups
+  constexpr int kFft15Batch = 4;
   if (m->fft_count[5]) {
     const size_t need = (size_t)hyena_fft15_scratch_bytes(std::min(m->fft_count[5], kFft15Batch), c.d_model);
     if (m->fft_scratch.bytes < need) {
-      DC_HIP_CHECK(hipStreamSynchronize(st));
-      if ((rc = ensure(m->fft_scratch, need))) return rc;
+      DC_HIP_CHECK(hipStreamSynchronize(st));  // earlier launches may still read the buffer about to be freed
+      // every (k1, b) of a (read, channel) is stored by the first kernel before the second one loads it: no zero fill
+      if ((rc = ensure(m->fft_scratch, need, /*zero_fill=*/false))) return rc;
     }
   }
 

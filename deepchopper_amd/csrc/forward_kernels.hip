@@ -1689,10 +1689,7 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   // LDS of the largest chunk: filter taps [32 + 32 * 32 * n_oc] + two z tiles
   const size_t lds = ((size_t)32 + 32 * 32 * (size_t)n_oc + 2 * 32 * HY_ZSTRIDE) * sizeof(float);
   DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
-  if (lds > 64 * 1024) {
-    DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena2_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel, 160 * 1024);  // the permitted maximum; a launch asks for `lds`
   hipLaunchKernelGGL(hyena2_kernel, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
   DC_LAUNCH_CHECK();
   return DC_OK;
@@ -2152,11 +2149,8 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 template <int MODE, bool TAB>
 static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
-  // per call: the attribute is per device (one process may drive several) and setting it is cheap
-  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<32, MODE, TAB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hyena3_kernel<16, MODE, TAB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<32, MODE, TAB>), lds);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<16, MODE, TAB>), lds);
   const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
   if (max_P <= 32 && !cb16) {
     hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);

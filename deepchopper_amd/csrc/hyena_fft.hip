@@ -737,9 +737,7 @@ constexpr size_t fft_smem() {
 template <int LOGM>
 int launch_filter_t(hipStream_t st, const float* kf, int64_t kf_stride, int kf_taps, int D, const float2* tw, float2* spec) {
   constexpr int T = (1 << LOGM) / 16;
-  // per call: the attribute is per device and the call is cheap (a process-wide `static bool` was neither)
-  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hyena_fft_filter_kernel<LOGM>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_smem<LOGM>()));
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fft_filter_kernel<LOGM>), fft_smem<LOGM>());
   hipLaunchKernelGGL(hyena_fft_filter_kernel<LOGM>, dim3(D), dim3(T), fft_smem<LOGM>(), st, kf, kf_stride, kf_taps, tw, spec);
   DC_LAUNCH_CHECK();
   return DC_OK;
@@ -748,8 +746,7 @@ int launch_filter_t(hipStream_t st, const float* kf, int64_t kf_stride, int kf_t
 template <int LOGM, bool TAB>
 int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
   constexpr int T = (1 << LOGM) / 16;
-  DC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hyena_fft_kernel<LOGM, TAB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_smem<LOGM>()));
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fft_kernel<LOGM, TAB>), fft_smem<LOGM>());
   hipLaunchKernelGGL((hyena_fft_kernel<LOGM, TAB>), dim3(n_reads, a.D), dim3(T), fft_smem<LOGM>(), st, a, reads, tw, spec);
   DC_LAUNCH_CHECK();
   return DC_OK;

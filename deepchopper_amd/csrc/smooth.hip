@@ -132,7 +132,19 @@ __global__ __launch_bounds__(BS, BS == 64 ? SM_OCC64 : 1) void smooth_kernel(Smo
       n = (int)(a.in_offsets[r + 1] - a.in_offsets[r]);
       lb = a.labels + a.in_offsets[r];
     }
-    if (n > CAPW * 64) n = CAPW * 64;  // host rejects longer reads / picks a larger form; defensive clamp
+    // Contract (include/deepchopper_hip.h): 0 <= first[r], first[r] + len[r] <= row_stride, and no read longer than this
+    // form's bit-vectors.  dc_tokenize_batch guarantees it; another caller's own lengths may not, and a silent clamp
+    // would hand back truncated labels and intervals that look valid (and the stripe loop would read past the row).
+    // Such a read is FLAGGED -- n_intervals[r] = n_keep[r] = -1, nothing else written for it -- and skipped.
+    bool bad = n > CAPW * 64;
+    if (FROM_LOGITS) bad = bad || a.first[r] < 0 || (int64_t)a.first[r] + n > a.row_stride;
+    if (bad) {  // block-uniform
+      if (threadIdx.x == 0) {
+        a.n_intervals[r] = -1;
+        if (a.n_keep) a.n_keep[r] = -1;
+      }
+      continue;
+    }
     if (n < 0) n = 0;
     const int nw = (n + 63) >> 6;
     const int n_pad = nw << 6;

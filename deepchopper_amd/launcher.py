@@ -37,15 +37,46 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def rank_env(rank: int, world: int, port: int, share_gpu: bool = False) -> dict:
+def cpu_plan(world: int, share_gpu: bool = False) -> dict | None:
+    """Where the workers and their parent run on the host (placement.plan): one disjoint slice of its GPU's NUMA node's
+    CPUs per rank.  None when placement is switched off or cannot be computed (never a reason to fail a run)."""
+    from . import placement
+
+    if not placement.enabled() or world < 2:
+        return None
+    try:
+        return placement.plan(world, local_devices=[0] * world if share_gpu else None)
+    except Exception:
+        return None
+
+
+def rank_env(rank: int, world: int, port: int, share_gpu: bool = False, plan: dict | None = None) -> dict:
     """Environment of worker `rank`: what torch.distributed.run would export.  share_gpu: every worker uses
-    device 0 (rehearsing the N > 1 path on a one-GPU box)."""
+    device 0 (rehearsing the N > 1 path on a one-GPU box).  `plan` (cpu_plan): the worker's CPU slice travels as
+    DC_CPUSET / DC_NUMA_NODE and is applied by the worker before it imports torch or touches the GPU
+    (placement.apply_for_this_rank); OMP_NUM_THREADS bounds torch's intra-op pool from its first CPU op on."""
+    from . import placement
+
     env = dict(os.environ)
     env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0" if share_gpu else str(rank),
                 "LOCAL_WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
                 "DC_SELF_LAUNCHED": "1"})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if plan is not None:
+        sl = plan["ranks"][rank]
+        env.update({"DC_CPUSET": placement.format_cpulist(sl["cpus"]), "DC_NUMA_NODE": str(sl["numa_node"]),
+                    "OMP_NUM_THREADS": str(len(sl["cpus"]))})
     return env
+
+
+def bind_parent(plan: dict | None) -> dict | None:
+    """The parent of a self-launched run (the node's single inflater) takes its own slice -- AFTER the workers were spawned,
+    so they do not inherit it."""
+    from . import placement
+
+    if plan is None or not plan.get("parent"):
+        return None
+    return placement.apply(plan["parent"]["cpus"])
 
 
 def spawn_ranks(argv: list[str], world: int, *, share_gpu: bool = False, extra_env: dict | None = None,
@@ -55,8 +86,9 @@ def spawn_ranks(argv: list[str], world: int, *, share_gpu: bool = False, extra_e
     the GPU.  stdout of every worker is piped back (its last line is the worker's JSON report)."""
     port = free_port()
     procs = []
+    plan = cpu_plan(world, share_gpu)
     for r in range(world):
-        env = rank_env(r, world, port, share_gpu)
+        env = rank_env(r, world, port, share_gpu, plan)
         if extra_env:
             env.update(extra_env)
         fds = pass_fds_per_rank[r] if pass_fds_per_rank else ()

@@ -50,6 +50,55 @@ def synth_reads_fixed(n_reads: int, length: int, seed: int = 42, plant: bool = T
     return bases, qual, ids
 
 
+def synth_fastq_fixed_fast(n_reads: int, length: int, seed: int = 42, start_index: int = 0, plant: bool = True) -> np.ndarray:
+    """FASTQ text (a flat uint8 array) of `n_reads` fixed-length reads, for the file legs of bench.py that need 10^6 reads in
+    seconds: the same distributions as `synth_reads_fixed` (bases iid uniform ACGT + 0.1 % N, Phred 1..40, ids
+    `read_{i:09d}`, PLANT in every other read) drawn more cheaply -- one splitmix64 output feeds eight bases (as
+    `synth_nanopore_like` does), one 16-bit piece gives a quality (`v * 40 >> 16`) and the N mask (`v & 1023 == 0`), and the
+    records are assembled as one [n, record] byte matrix.  NOT the same bytes as `synth_reads_fixed` for a given seed.
+    numpy releases the GIL in all of it: callers generate blocks on a thread pool."""
+    total = n_reads * length
+    r = splitmix64(seed, (total + 7) // 8, stream=100 + 2 * start_index).view(np.uint8)[:total]
+    v = splitmix64(seed, (total + 3) // 4, stream=101 + 2 * start_index).view(np.uint16)[:total]
+    rec = 1 + 14 + 1 + length + 3 + length + 1
+    out = np.empty((n_reads, rec), np.uint8)
+    out[:, 0] = ord("@")
+    out[:, 1:6] = np.frombuffer(b"read_", np.uint8)
+    idx = np.arange(start_index, start_index + n_reads, dtype=np.int64)
+    for d in range(9):
+        out[:, 6 + d] = 48 + (idx // 10 ** (8 - d)) % 10
+    out[:, 15] = 10
+    seq = out[:, 16: 16 + length]
+    seq[:] = np.frombuffer(b"ACGT" * 64, np.uint8)[r].reshape(n_reads, length)
+    seq[((v & np.uint16(1023)) == 0).reshape(n_reads, length)] = ord("N")  # 1 / 1024
+    out[:, 16 + length: 19 + length] = np.frombuffer(b"\n+\n", np.uint8)
+    out[:, 19 + length: 19 + 2 * length] = (34 + ((v.astype(np.uint32) * np.uint32(40)) >> np.uint32(16))).astype(np.uint8).reshape(
+        n_reads, length)
+    out[:, rec - 1] = 10
+    if plant and length >= len(PLANT) + 2:
+        rows = np.arange(0, n_reads, 2)
+        pos = 1 + (splitmix64(seed, n_reads, stream=102 + 2 * start_index)[rows] % np.uint64(length - len(PLANT) - 1)).astype(np.int64)
+        seq[rows[:, None], pos[:, None] + np.arange(len(PLANT))] = np.frombuffer(PLANT, np.uint8)
+    return out.reshape(-1)
+
+
+def write_fastq_fixed_fast(path: str, n_reads: int, length: int, seed: int = 42, block: int = 20_000, threads: int = 8) -> int:
+    """`n_reads` reads of `synth_fastq_fixed_fast` into `path`, blocks generated on `threads` threads and written in order.
+    Returns the bytes written."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    starts = list(range(0, n_reads, block))
+    written = 0
+    with ThreadPoolExecutor(max(1, threads)) as ex, open(path, "wb") as fh:
+        for w0 in range(0, len(starts), 2 * threads):  # bounded look-ahead: 2 blocks per thread in memory
+            futs = [ex.submit(synth_fastq_fixed_fast, min(block, n_reads - b0), length, seed, b0) for b0 in starts[w0: w0 + 2 * threads]]
+            for f in futs:
+                buf = f.result()
+                fh.write(memoryview(buf))
+                written += buf.size
+    return written
+
+
 def synth_reads_mixed(n_reads: int, min_len: int = 100, max_len: int = 10000, seed: int = 42):
     """Log-uniform lengths in [min_len, max_len] (config C4).  Returns lists of bytes."""
     u = uniform01(seed, n_reads, stream=7)

@@ -134,7 +134,15 @@ int dc_kmer_vectorize_targets(void* stream, const int32_t* d_ranges, int32_t n_r
  *  d_intervals  : int32[n_reads,max_intervals,2]; d_n_intervals int32[n_reads]
  *                 (0 when the filtered count exceeds `approved`, like the reference)
  *  d_keep       : int32[n_reads,max_intervals+1,2] kept segments; d_n_keep int32[n_reads]
- *                 (either may be NULL).  max_intervals must be >= approved. */
+ *                 (either may be NULL).  max_intervals must be >= approved.
+ *
+ *  Contract on the lengths (they live on the device, so the host cannot check them):
+ *  0 <= d_first[r], d_first[r] + d_len[r] <= row_stride, d_len[r] <= 65 536 (the kernel form --
+ *  2 048 / 4 096 / 65 536 positions -- is picked from row_stride alone).  dc_tokenize_batch's
+ *  outputs satisfy it.  A read that violates it is not truncated silently: the kernel writes
+ *  d_n_intervals[r] = -1 (and d_n_keep[r] = -1) and nothing else for that read; the other reads of
+ *  the launch are unaffected.  The same flag marks a read longer than 65 536 positions in
+ *  dc_smooth_intervals_from_labels. */
 int dc_smooth_intervals_from_logits(void* stream, const float* d_logits, int64_t row_stride,
                                     const int32_t* d_first, const int32_t* d_len, int32_t n_reads,
                                     const int64_t* d_out_offsets, int32_t window,

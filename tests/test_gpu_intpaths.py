@@ -439,3 +439,28 @@ def test_summary_predict(env, kats):
     ep, el = o.summary_predict(pred, lab, -100)
     for r in range(17):
         assert np.array_equal(op[offs[r]: offs[r + 1]], ep[r]) and np.array_equal(ol[offs[r]: offs[r + 1]], el[r])
+
+
+@pytest.mark.parametrize("row_stride", [600, 3000, 5000])  # the 64-, 128- and 256-thread forms
+def test_smooth_flags_reads_whose_lengths_break_the_contract(env, row_stride):
+    """include/deepchopper_hip.h: first[r] + len[r] <= row_stride.  A caller's inconsistent length must not come back as
+    truncated labels / intervals that look valid: the read is flagged n_intervals = n_keep = -1, its neighbours are
+    computed as usual (the kernel used to clamp n to its form's capacity silently)."""
+    torch, ops = env
+    from oracle import dc_oracle as o
+
+    rng = np.random.default_rng(row_stride)
+    B = 5
+    logits = rng.standard_normal((B, row_stride, 2)).astype(np.float32)
+    first = np.array([0, 10, 5, 0, row_stride - 40], np.int32)
+    length = np.array([row_stride, row_stride - 10, row_stride, row_stride + 4000, 40], np.int32)  # rows 2, 3 overrun
+    first_bad = first.copy()
+    out = ops.smooth_intervals_from_logits(ops.to_device(logits), ops.to_device(first_bad), ops.to_device(length),
+                                           window=21, min_interval=13, approved=20, want_labels=False)
+    niv, nkeep = out["n_intervals"].cpu().numpy(), out["n_keep"].cpu().numpy()
+    iv = out["intervals"].cpu().numpy()
+    assert niv[2] == -1 and niv[3] == -1 and nkeep[2] == -1 and nkeep[3] == -1
+    for b in (0, 1, 4):
+        lab = (logits[b, first[b]: first[b] + length[b], 1] > logits[b, first[b]: first[b] + length[b], 0]).astype(np.int8)
+        want = o.smooth_label_region(lab, 21, 13, 20)
+        assert niv[b] == len(want) and [tuple(x) for x in iv[b, : niv[b]].tolist()] == want

@@ -1,0 +1,315 @@
+"""The legs of bench.py beside its headline: one per BASELINE.json config, so that the driver's record carries every config
+at its stated shape (N = 1 only; none of them is `value`).  Each leg times the product path and then checks it -- against
+the CPU oracle on a bounded sample (the oracle is the checker here, never the thing measured), or through record counts.
+
+    configs.c1_512bp            configs[0]  1 000 x 512 bp reads, HBM-resident step loop (the whole config per step) + a 4 096-read batch
+    configs.c3_2kb_1gpu_slice   configs[2]  2 kb reads, one GPU's slice of the read-sharded run, HBM-resident step loop
+    configs.c4_mixed            configs[3]  log-uniform 100 bp - 10 kb FASTQ file -> predict_stream (token-budget batches) -> intervals
+    configs.c5_gz_chop          configs[4]  nanopore-like .fastq.gz -> fused predict -> chop -> BGZF (-t 4), adapters planted
+    file_e2e                    configs[1]  1 000 000 x 1 kb reads, FASTQ file -> labels + intervals, first vs last 100 k reads
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import shutil
+import tempfile
+import time
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the checker
+# ------------------------------------------------------------------------------------------------------------
+def oracle_reads(sd, names, seqs, quals, batch: int = 12):
+    """Oracle labels / smoothed labels / intervals for reads of EQUAL length (left-padding-free batches of `batch`, the
+    reference's default batch size) or, with batch = 1, for any reads at their own length."""
+    from oracle import dc_oracle as o
+    from oracle import forward_ref as fr
+
+    out = {}
+    feats = []
+    for i, s, q in zip(names, seqs, quals):
+        rec = o.parse_fastq_record(i, s.decode("latin1"), q.decode("latin1"))
+        feats.append(o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"]))
+    for b0 in range(0, len(feats), batch):
+        b = o.collate(feats[b0: b0 + batch])
+        logits = fr.forward(sd, b["input_ids"], b["input_quals"]).numpy()
+        preds = o.load_predicts_from_batch({"prediction": logits, "target": b["labels"], "seq": b["input_ids"], "id": b["id"]})
+        for rid, p in preds.items():
+            out[rid] = (p.prediction, p.smooth_label(21), p.smooth_and_select_intervals(21, 13, 20))
+    return out
+
+
+def f1_check(expected: dict, got: dict) -> dict:
+    """expected / got: {read id: (labels int8[n], intervals [(s, e), ...])} -> per-base F1 of label 1 and interval identity."""
+    tp = fp = fn = 0
+    same_iv = same_lab = True
+    for rid, (e_lab, _, e_iv) in expected.items():
+        g_lab, g_iv = got[rid]
+        tp += int(np.sum((g_lab == 1) & (e_lab == 1)))
+        fp += int(np.sum((g_lab == 1) & (e_lab == 0)))
+        fn += int(np.sum((g_lab == 0) & (e_lab == 1)))
+        same_lab &= bool(np.array_equal(g_lab, e_lab))
+        same_iv &= [tuple(x) for x in g_iv] == [tuple(x) for x in e_iv]
+    f1 = 1.0 if (fp + fn) == 0 else 2 * tp / max(2 * tp + fp + fn, 1)
+    return {"reads": len(expected), "per_base_f1_vs_oracle": round(f1, 6), "labels_identical": bool(same_lab),
+            "intervals_identical": bool(same_iv)}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# HBM-resident step loops at other read lengths (configs[0], configs[2])
+# ------------------------------------------------------------------------------------------------------------
+def resident_leg(pipe, sd, B: int, L: int, steps: int, what: str, check_reads: int = 12) -> dict:
+    import torch
+
+    from deepchopper_amd import ops, synth
+
+    seq, qual, ids = synth.synth_reads_fixed(B, L, seed=42)
+    offs = np.arange(B + 1, dtype=np.int64) * L
+    d = (ops.to_device(seq.reshape(-1)), ops.to_device(qual.reshape(-1)), ops.to_device(offs))
+    lens = np.full(B, L, np.int64)
+    for _ in range(2):
+        res = pipe.run_device_batch(*d, lens, want_labels=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = pipe.run_device_batch(*d, lens, want_labels=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": what, "value": round(B * steps / dt, 1), "unit": "reads/s", "Mbases_per_s": round(B * steps * L / dt / 1e6, 2),
+           "reads_per_step": B, "read_len": L, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3)}
+    if check_reads:
+        n = min(check_reads, B)
+        exp = oracle_reads(sd, ids[:n], [seq[i].tobytes() for i in range(n)], [qual[i].tobytes() for i in range(n)])
+        o = res["smooth"]["offsets"].cpu().numpy()
+        pred = res["smooth"]["pred"].cpu().numpy()
+        iv, niv = res["smooth"]["intervals"].cpu().numpy(), res["smooth"]["n_intervals"].cpu().numpy()
+        got = {ids[r]: (pred[o[r]: o[r + 1]], iv[r, : niv[r]].tolist()) for r in range(n)}
+        out["check"] = f1_check(exp, got)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[3]: mixed lengths from a file
+# ------------------------------------------------------------------------------------------------------------
+def mixed_leg(pipe, sd, n_reads: int, check_reads: int = 6) -> dict:
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader
+
+    seqs, quals, ids = synth.synth_reads_mixed(n_reads, 100, 10000, seed=42)
+    bases = sum(len(s) for s in seqs)
+    tmp = tempfile.mkdtemp(prefix="dc_c4_")
+    path = os.path.join(tmp, "mixed.fq")
+    try:
+        with open(path, "wb") as fh:
+            fh.write(synth.to_fastq(seqs, quals, ids))
+        # warm-up on the head of the file: every FFT size class, both Toeplitz forms, pinned staging
+        with FastqReader(path) as rd:
+            for i, _ in enumerate(pipe.predict_stream(rd.chunks(8192, 2_000_000))):
+                if i >= 3:
+                    break
+        torch.cuda.synchronize()
+        want = {ids[i] for i in range(min(400, n_reads)) if len(seqs[i]) <= 1500}
+        want = set(sorted(want)[:check_reads])
+        got = {}
+        t0 = time.perf_counter()
+        nr = n_iv = 0
+        with FastqReader(path) as rd:
+            for res in pipe.predict_stream(rd.chunks(8192, 2_000_000)):
+                nr += len(res["names"])
+                n_iv += int(res["n_intervals"].sum())
+                if want:  # (a set lookup per read of the first chunks only; nothing once the sample is complete)
+                    for r, name in enumerate(res["names"]):
+                        if name in want:
+                            o = res["offsets"]
+                            got[name] = (np.array(res["pred"][o[r]: o[r + 1]]), res["intervals"][r, : res["n_intervals"][r]].tolist())
+                            want.discard(name)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"workload": "configs[3]: log-uniform 100 bp - 10 kb reads, FASTQ file -> parse -> token-budget batches (2 M tokens) -> "
+                       "tokenise/forward/smooth -> labels + intervals on the host (predict_stream)",
+           "value": round(nr / dt, 1), "unit": "reads/s", "Mbases_per_s": round(bases / dt / 1e6, 2), "reads": nr,
+           "mean_bp": round(bases / n_reads, 1), "seconds": round(dt, 3), "intervals": n_iv}
+    if got:
+        idx = {n: i for i, n in enumerate(ids)}
+        names = sorted(got)
+        exp = oracle_reads(sd, names, [seqs[idx[n]] for n in names], [quals[idx[n]] for n in names], batch=1)
+        out["check"] = f1_check(exp, got)
+        out["check"]["what"] = "every sampled read at its own length == the reference at --batch-size 1 (SURVEY 0.6)"
+    assert nr == n_reads, (nr, n_reads)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[4]: .fastq.gz -> predict -> chop -> BGZF
+# ------------------------------------------------------------------------------------------------------------
+def _count_output(path: str) -> dict:
+    from deepchopper_amd.fastq import FastqReader
+
+    n = n_t = n_i = bases = 0
+    with FastqReader(path) as rd:
+        for c in rd.chunks(65536, 256 << 20):
+            raw, o = c._names.tobytes(), c._name_offsets
+            n += c.n
+            bases += int(c.offsets[c.n])
+            for k in range(c.n):
+                tail = raw[o[k + 1] - 2: o[k + 1]]
+                n_t += tail == b"|T"
+                n_i += tail == b"|I"
+    return {"records": n, "terminal_chops": int(n_t), "internal_chop_segments": int(n_i), "passed_through": int(n - n_t - n_i),
+            "bases_out": bases}
+
+
+def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24) -> dict:
+    """Nanopore-like reads (log-normal lengths, ONT headers, adapters planted as runs of the base the token-gated
+    weights label 1) -> gzip file -> `predict_chop` (the body of `deepchopper predict --chop`) -> chopped BGZF.
+    Checks: (1) the head of the output file equals, byte for byte, what the oracle's forward + `chop_read` emit for the
+    first `check_reads` reads; (2) the whole file parses and its record count is the one the driver reported."""
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.chop import predict_chop
+    from deepchopper_amd.model import DeepChopper
+    from deepchopper_amd.predict import PredictPipeline
+    from deepchopper_amd.weights import token_gated_state_dict
+
+    tmp = tempfile.mkdtemp(prefix="dc_c5_")
+    cwd = os.getcwd()
+    try:
+        path = os.path.join(tmp, "hct116_like.fastq.gz")
+        t0 = time.perf_counter()
+        n_bases = 0
+        head = None
+        with gzip.open(path, "wb", compresslevel=1) as fh:
+            for b0 in range(0, n_reads, 50_000):
+                n = min(50_000, n_reads - b0)
+                h, s, q = synth.synth_nanopore_like(n, seed=42 + b0, start_index=b0)
+                if head is None:
+                    head = (h[:check_reads], s[:check_reads], q[:check_reads])
+                n_bases += sum(len(x) for x in s)
+                fh.write(synth.fastq_text(h, s, q))
+        gen_s = time.perf_counter() - t0
+        sd = token_gated_state_dict(0)
+        pipe = PredictPipeline(DeepChopper.from_state_dict(sd))
+        os.chdir(tmp)
+        warm = os.path.join(tmp, "warm.fastq")
+        h, s, q = synth.synth_nanopore_like(20_000, seed=7)
+        with open(warm, "wb") as fh:
+            fh.write(synth.fastq_text(h, s, q))
+        final, _, _ = predict_chop(warm, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000)
+        os.remove(final)
+        os.remove(warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        final, n_in, n_out = predict_chop(path, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"workload": "configs[4] flow on one GPU: nanopore-like reads (log-normal lengths, ONT headers, adapters planted), plain "
+                           ".fastq.gz -> parallel inflate -> predict -> chop (src/bin/predict.rs:130-192) -> BGZF, no .pt in between",
+               "value": round(n_in / dt, 1), "unit": "reads/s", "Mbases_per_s": round(n_bases / dt / 1e6, 2), "reads": n_in,
+               "mean_bp": round(n_bases / n_reads, 1), "seconds": round(dt, 3), "bgzf_threads": threads,
+               "input_MB": round(os.path.getsize(path) / 1e6, 1), "output_MB": round(os.path.getsize(final) / 1e6, 1),
+               "generate_s": round(gen_s, 1)}
+        counts = _count_output(final)
+        out.update(counts)
+        check = {"records_match_driver_report": counts["records"] == n_out, "reads_in_match": n_in == n_reads,
+                 "bases_out_le_bases_in": counts["bases_out"] <= n_bases}
+        if check_reads:
+            check.update(_chop_head_check(sd, head, final))
+        out["check"] = check
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def _chop_head_check(sd, head, final_path: str) -> dict:
+    """The first reads through the oracle: tokenise -> forward (torch fp32) -> argmax -> chop_read, compared with the head
+    of the chopped file byte for byte."""
+    from oracle import dc_oracle as o
+    from oracle import forward_ref as fr
+
+    headers, seqs, quals = head
+    want = []
+    for h, s, q in zip(headers, seqs, quals):
+        name = h.split(b" ", 1)[0]
+        rec = o.parse_fastq_record(name.decode(), s.decode(), q.decode())
+        f = o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"])
+        b = o.collate([f])
+        logits = fr.forward(sd, b["input_ids"], b["input_quals"]).numpy()
+        p = o.load_predicts_from_batch({"prediction": logits, "target": b["labels"], "seq": b["input_ids"], "id": b["id"]})[name.decode()]
+        for rid, rs, rq in o.chop_read(p, name, s, q, fq_header=h):  # the chop binary's defaults (src/bin/predict.rs:39-64)
+            want.append(b"@" + rid + b"\n" + rs + b"\n+\n" + rq + b"\n")
+    want = b"".join(want)
+    with gzip.open(final_path, "rb") as fh:
+        got = fh.read(len(want))
+    return {"head_reads_vs_oracle": len(headers), "head_bytes_identical": got == want}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[1] from a file, at its stated size
+# ------------------------------------------------------------------------------------------------------------
+def file_e2e_leg(pipe, sd, n_reads: int, read_len: int, batch: int, check_reads: int = 12, gen_threads: int = 8) -> dict:
+    """FASTQ-inclusive rate ("FASTQ bytes in -> per-base labels + intervals out") over `n_reads` reads --
+    configs[1] says 1 000 000 x 1 kb: about half a minute of sustained work, so clock droop shows: the rate over the first
+    and over the last 100 000 reads is reported next to the whole run's."""
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader
+
+    tmp = tempfile.mkdtemp(prefix="dc_bench_")
+    path = os.path.join(tmp, "reads.fq")
+    try:
+        t0 = time.perf_counter()
+        nbytes = synth.write_fastq_fixed_fast(path, n_reads, read_len, seed=42, threads=gen_threads)
+        gen_s = time.perf_counter() - t0
+        cap = batch * (read_len + 1)
+        with FastqReader(path) as rd:  # warm-up: pinned staging, copy stream
+            for i, _ in enumerate(pipe.predict_stream(rd.chunks(batch, cap))):
+                if i >= 2:
+                    break
+        torch.cuda.synchronize()
+        marks = [(0, time.perf_counter())]
+        n = n_iv = 0
+        first = None
+        t0 = marks[0][1]
+        with FastqReader(path) as rd:
+            for res in pipe.predict_stream(rd.chunks(batch, cap)):
+                if first is None and check_reads:
+                    o = res["offsets"]
+                    first = {"names": res["names"][:check_reads],
+                             "seq": [bytes(res["seq"][res["in_offsets"][r]: res["in_offsets"][r + 1]]) for r in range(check_reads)],
+                             "qual": [bytes(res["qual"][res["in_offsets"][r]: res["in_offsets"][r + 1]]) for r in range(check_reads)],
+                             "got": {res["names"][r]: (np.array(res["pred"][o[r]: o[r + 1]]),
+                                                       res["intervals"][r, : res["n_intervals"][r]].tolist()) for r in range(check_reads)}}
+                n += len(res["names"])
+                n_iv += int(res["n_intervals"].sum())
+                marks.append((n, time.perf_counter()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def rate_between(lo: int, hi: int):
+        a = next(m for m in marks if m[0] >= lo)
+        b = next(m for m in reversed(marks) if m[0] <= hi)
+        return round((b[0] - a[0]) / (b[1] - a[1]), 1) if b[0] > a[0] else None
+
+    out = {"value": round(n / dt, 1), "unit": "reads/s", "reads": n, "seconds": round(dt, 3), "container": "plain FASTQ",
+           "file_GB": round(nbytes / 1e9, 3), "generate_s": round(gen_s, 1), "intervals": n_iv,
+           "what": "file -> parse -> H2D -> tokenise/forward/smooth -> D2H labels + intervals (predict_stream)"}
+    if n >= 300_000:
+        out["first_100k_reads_per_s"] = rate_between(0, 100_000)
+        out["last_100k_reads_per_s"] = rate_between(n - 100_000, n)
+    if first is not None:
+        exp = oracle_reads(sd, first["names"], first["seq"], first["qual"])
+        out["check"] = f1_check(exp, first["got"])
+        out["check"]["reads_counted"] = n == n_reads
+    return out
