@@ -169,8 +169,10 @@ def test_forward_is_causal_and_pad_prefix_is_row_independent(env, L, path, stage
 
     The block-Toeplitz MFMA kernel is exactly causal (its blocks above the diagonal are exactly zero), so both hold BIT FOR
     BIT there.  The FFT forms compute what the reference's `fftconv` computes -- a circular convolution of the whole row
-    -- so later tokens reach earlier outputs as fp32 rounding noise (the reference has the same property); held to 5e-5,
-    20 times inside north_star's 1e-3."""
+    -- so later tokens reach earlier outputs as fp32 rounding noise.  The reference has the same property: the torch-fp32
+    oracle's own pad-prefix difference at 3 000 tokens is 5.6e-5 (tests/test_reference_fixture_model.py measures it on
+    the CPU); the HIP FFT forms are held to 2e-4 here -- the parity tolerance of this file, 5 times inside north_star's
+    1e-3 and five orders of magnitude below a real look-ahead (the CNN fixtures differ by ~80)."""
     torch, ops, sd, model = env
     rng = np.random.default_rng(L)
     B = 4
@@ -192,7 +194,7 @@ def test_forward_is_causal_and_pad_prefix_is_row_independent(env, L, path, stage
     else:
         assert stages.get("hyena_fft", (0, 0))[1] == 0 and stages.get("hyena_fft15", (0, 0))[1] == 0, (path, stages)
     exact = stage is None
-    tol = 0.0 if exact else 5e-5
+    tol = 0.0 if exact else ATOL
 
     def same(x, y, what):
         if exact:

@@ -555,7 +555,22 @@ def test_multi_rank_chop_output_is_in_input_order_and_byte_identical_to_one_gpu(
     one = run([sys.executable, "-m", "deepchopper_amd.cli"] + common + ["-g", "1"], tmp_path / "one")
     kind, n = launch.split("-")
     if kind == "self":
-        many = run([sys.executable, "-m", "deepchopper_amd.cli"] + common + ["-g", n], tmp_path / "many")
+        rep = tmp_path / "report.json"
+        many = run([sys.executable, "-m", "deepchopper_amd.cli"] + common + ["-g", n, "--report-json", str(rep)], tmp_path / "many")
+        # CPU placement (deepchopper_amd/placement.py): every worker bound to its own slice of the GPU's NUMA node's CPUs,
+        # torch's intra-op pool bounded by the slice, the parent (single inflater) on CPUs none of them uses
+        import json
+
+        from deepchopper_amd.placement import parse_cpulist
+
+        report = json.load(open(rep))
+        sets = [set(parse_cpulist(r["cpuset"])) for r in report["ranks"]]
+        assert all(0 < len(c) <= 5 for c in sets), report["cpusets"]
+        assert all(not (sets[i] & sets[j]) for i in range(len(sets)) for j in range(i + 1, len(sets))), report["cpusets"]
+        assert all(r["torch_threads"] == len(c) for r, c in zip(report["ranks"], sets))
+        assert len({r["numa_node"] for r in report["ranks"]}) == 1  # the ranks share this box's one GPU, hence its node
+        if report["cpusets"]["parent"]:
+            assert not (set(parse_cpulist(report["cpusets"]["parent"])) & set().union(*sets))
     else:
         many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                     "--master-port", "29617", "-m", "deepchopper_amd.cli"] + common + ["-g", n], tmp_path / "many")

@@ -81,3 +81,26 @@ def test_oracle_forward_is_causal_where_the_fixtures_are_not():
     worst, pairs = real_ckpt.max_lookahead(got, ids)
     assert pairs == 3 and worst < 1e-4
     assert real_ckpt.require_causal({"prediction": got, "seq": ids}, "oracle") == 3
+
+
+def test_fft_long_convolution_leaks_rounding_noise_backwards_in_the_reference_too():
+    """Why tests/test_gpu_forward.py::test_forward_is_causal_... holds the FFT forms to a tolerance and only the block-Toeplitz
+    form to bit-identity: the reference's own `fftconv` (2L-point rfft/irfft; oracle/forward_ref.py:68-77) is a circular
+    convolution of the whole row in fp32, so what follows position t reaches the outputs before t as rounding noise --
+    O(1e-5) on O(1) logits at 3 000 tokens.  Measured here on the oracle; far below the 1e-2 the causality gate of the
+    replay harness allows, and nothing like a receptive field."""
+    from deepchopper_amd.weights import synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(3000)
+    B, L = 2, 3000
+    ids = rng.integers(7, 12, (B, L)).astype(np.int64)
+    q = rng.integers(1, 41, (B, L)).astype(np.float32)
+    ids[:, -1], q[:, -1] = 1, 0
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    for b, n in enumerate((L // 2, L // 5)):
+        ids[b, :n] = real_ckpt.PAD_ID
+        q[b, :n] = 0
+    got = fr.forward(synthetic_state_dict(0), ids, q).numpy()
+    worst, pairs = real_ckpt.max_lookahead(got, ids)
+    assert pairs == 1 and 1e-7 < worst < 2e-4, worst
