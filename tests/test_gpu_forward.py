@@ -486,9 +486,63 @@ def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
     assert np.array_equal(outs[True][1], outs[False][1])
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "fp16x3"])
+@pytest.mark.parametrize("gpw", [None, "1", "3"])
+def test_warp_specialised_long_convolution_is_bit_identical_to_hyena3(hip_lib, monkeypatch, mode, gpw):
+    """csrc/hyena_ws_kernel.inc (producer waves build the gated-input tiles and finish the output blocks, consumer waves
+    only run MFMAs; a workgroup streams several 32-read groups of its channel) against hyena3_kernel<32> of the same build
+    (DC_H3_WS=0): same arithmetic in the same order, so the logits must be BIT-identical -- on ragged batches whose groups
+    differ in length (1 .. 32 blocks per group, groups with empty read slots, reads that end inside a block), on a dense
+    left-padded batch, with the layer-0 token-table gather and without it, and for every groups-per-workgroup setting."""
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+
+    if gpw is not None:
+        monkeypatch.setenv("DC_H4_GPW", gpw)
+    sd = synthetic_state_dict(77)
+    rng = np.random.default_rng(77)
+    lens = np.concatenate([rng.integers(1, 1025, 150), [1, 2, 3, 4, 5, 31, 32, 33, 64, 65, 992, 993, 1023, 1024] * 2,
+                           np.full(70, 1001)]).astype(np.int32)
+    B, stride = len(lens), int(lens.max())
+    ids = np.full((B, stride), 4, np.uint8)
+    q = np.zeros((B, stride), np.float32)
+    first = (stride - lens).astype(np.int32)
+    for b, n in enumerate(lens):
+        i1, q1 = _inputs(rng, 1, int(n))
+        ids[b, stride - n:], q[b, stride - n:] = i1[0], q1[0]
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    dense_ids, dense_q = _inputs(rng, 37, 700, pad_max=300)
+    dd_ids, dd_q = ops.to_device(dense_ids.astype(np.uint8)), ops.to_device(dense_q)
+    out = {}
+    for ws in ("1", "0"):
+        for l0 in ("0", "1"):
+            monkeypatch.setenv("DC_H3_WS", ws)
+            if l0 == "1":
+                monkeypatch.setenv("DC_NO_L0_GATHER", "1")
+            else:
+                monkeypatch.delenv("DC_NO_L0_GATHER", raising=False)
+            model = ops.HipModel(sd, HyenaDNAConfig())
+            model.set_gemm_mode(mode)
+            model.set_profiling(True)
+            model.profile_reset()
+            a = model.forward_ragged(d_ids, d_q, first, lens).cpu().numpy()
+            b = model.forward(dd_ids, dd_q).cpu().numpy()
+            assert model.profile().get("hyena", (0, 0))[1] == 8 and model.profile().get("hyena_fft", (0, 0))[1] == 0
+            assert model.overflow() == 0 if mode == "fp16x3" else True
+            out[(ws, l0)] = (a, b)
+            model.close()
+    for l0 in ("0", "1"):
+        for i in (0, 1):
+            x, y = out[("1", l0)][i], out[("0", l0)][i]
+            assert np.isfinite(x).all()
+            assert np.array_equal(x, y), f"ws vs hyena3 ({mode}, no-l0-gather={l0}, {'ragged' if i == 0 else 'dense'}): max |d| = {np.abs(x - y).max():.3e}"
+    for b, n in enumerate(lens):
+        assert np.all(out[("1", "0")][0][b, : stride - n] == 0)
+
+
 AB_SWITCHES = [("DC_NO_HEAD_FUSE", "1"), ("DC_NO_FUSED_STATS", "1"), ("DC_NO_L0_TABLE", "1"), ("DC_NO_L0_GATHER", "1"),
                ("DC_NO_MLP_CHAIN", "1"), ("DC_NO_MLP_FUSE", "1"), ("DC_HYENA", "2"), ("DC_H3_ONE_LAUNCH", "1"),
-               ("DC_H3_CB16", "1")]
+               ("DC_H3_CB16", "1"), ("DC_H3_WS", "0")]
 
 
 @pytest.mark.parametrize("name,value", AB_SWITCHES, ids=[n for n, _ in AB_SWITCHES])

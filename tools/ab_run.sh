@@ -6,7 +6,7 @@ for lib in deepchopper_amd/lib/libdc_*.so; do
   name=$(basename "$lib" .so)
   for rep in 1 2; do
     if ! DC_HIP_LIB=$PWD/$lib timeout -k 5 200 python bench.py --steps 4 --warmup 2 --batch "${AB_BATCH:-1024}" --cpu-seconds 0 \
-          --strict-steps 0 --e2e-reads 0 ${AB_ARGS} 2>/dev/null | python tools/bench_stages.py "$name"; then
+          --strict-steps 0 --e2e-reads 0 --legs "" ${AB_ARGS} 2>/dev/null | python tools/bench_stages.py "$name"; then
       echo "$name FAILED (bench.py exit status ${PIPESTATUS[0]})"
     fi
   done
