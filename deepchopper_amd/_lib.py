@@ -13,7 +13,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DC_HIP_LIB") or os.path.join(_HERE, "lib", "libdeepchopper_hip.so")  # override: kernel A/B experiments
-HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h")
+# the C-ABI header: shipped inside an installed package (setup.py copies include/*.h there), in the repo next to the package
+HEADER_PATH = next((p for p in (os.path.join(_HERE, "include", "deepchopper_hip.h"), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h"))
+                    if os.path.exists(p)), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h"))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 
