@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --no-profile"
+ARGS="--steps 4 --warmup 1 --cpu-seconds 0 --strict-steps 0 --e2e-reads 0 --legs \"\" --no-profile"
 i=0
 for grp in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
@@ -21,7 +21,7 @@ cd $R
 {
   for j in 1 2 3 4; do
     echo "== pass $j"
-    python3 tools/pmc_util.py $O/${TAG}_pmc_u$j mlp_fused gemm6_kernel hyena3
+    python3 tools/pmc_util.py $O/${TAG}_pmc_u$j mlp_fused gemm6_kernel hyena
   done
 } > $O/${TAG}_pmc_util.txt 2>&1
 find $O/${TAG}_pmc_u? -type f -size +2M -delete
