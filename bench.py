@@ -444,22 +444,30 @@ def main():
         if world == 1:
             from tools import bench_legs
 
+            def leg(fn, *a, **kw):
+                """A leg reports beside the headline; it must never take the line down with it (a full /tmp, a missing gzip ...)."""
+                try:
+                    return fn(*a, **kw)
+                except Exception as e:
+                    return {"error": f"{type(e).__name__}: {e}"}
+
             legs = [x for x in args.legs.split(",") if x]
             if args.e2e_reads > 0:
-                e2e = bench_legs.file_e2e_leg(pipe, sd, args.e2e_reads, L, B)
+                e2e = leg(bench_legs.file_e2e_leg, pipe, sd, args.e2e_reads, L, B)
             if "c1" in legs:
-                configs["c1_512bp"] = bench_legs.resident_leg(
-                    pipe, sd, 1000, 512, 40, "configs[0]: 1 000 synthetic 512-bp reads = one step (the whole config), HBM-resident")
-                configs["c1_512bp"]["batch_4096"] = bench_legs.resident_leg(
-                    pipe, sd, 4096, 512, 10, "512-bp reads in batches of 4 096 (the shape's best batch)", check_reads=0)
+                configs["c1_512bp"] = leg(bench_legs.resident_leg, pipe, sd, 1000, 512, 40,
+                                          "configs[0]: 1 000 synthetic 512-bp reads = one step (the whole config), HBM-resident")
+                configs["c1_512bp"]["batch_4096"] = leg(bench_legs.resident_leg, pipe, sd, 4096, 512, 10,
+                                                        "512-bp reads in batches of 4 096 (the shape's best batch)", check_reads=0)
             if "c3" in legs:
-                configs["c3_2kb_1gpu_slice"] = bench_legs.resident_leg(
-                    pipe, sd, 1024, 2000, 12, "configs[2]: synthetic 2 kb reads, ONE GPU's slice of the read-sharded run "
-                                                "(1 024 reads per step; 8 ranks run 8 of these with no exchange), HBM-resident")
+                configs["c3_2kb_1gpu_slice"] = leg(
+                    bench_legs.resident_leg, pipe, sd, 1024, 2000, 12,
+                    "configs[2]: synthetic 2 kb reads, ONE GPU's slice of the read-sharded run (1 024 reads per step; 8 ranks run "
+                    "8 of these with no exchange), HBM-resident")
             if "c4" in legs:
-                configs["c4_mixed"] = bench_legs.mixed_leg(pipe, sd, args.c4_reads)
+                configs["c4_mixed"] = leg(bench_legs.mixed_leg, pipe, sd, args.c4_reads)
             if "c5" in legs:
-                configs["c5_gz_chop"] = bench_legs.gz_chop_leg(args.c5_reads, threads=4)
+                configs["c5_gz_chop"] = leg(bench_legs.gz_chop_leg, args.c5_reads, threads=4)
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",

@@ -593,6 +593,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 // dc_debug_read_stamps() (tools/ab_run.sh prints it when the symbol exists).
 __device__ unsigned long long dc_stamps[8][4];
 __device__ unsigned long long dc_stamps_rt[8];  // wave-summed s_memrealtime (100 MHz) ticks, whole kernel
+__device__ unsigned long long dc_stamps_h4[4][4];  // hyena4 roles (consumer, Z, Y) x {prologue, working, at the barrier, waves}
 #define DC_STAMP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define DC_STAMP_T(var)
@@ -2351,6 +2352,8 @@ extern "C" int dc_debug_read_stamps(unsigned long long* out) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dc::dc_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(dc::dc_stamps_rt), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
   unsigned long long zero[32] = {0};
+  if (hipMemcpyFromSymbol(out + 40, HIP_SYMBOL(dc::dc_stamps_h4), sizeof(unsigned long long) * 16) != hipSuccess) return 1;  // out[56]
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dc::dc_stamps_h4), zero, sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(dc::dc_stamps_rt), zero, sizeof(unsigned long long) * 8) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(dc::dc_stamps), zero, sizeof zero) == hipSuccess ? 0 : 1;
 }

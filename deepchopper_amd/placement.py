@@ -207,6 +207,13 @@ def apply_for_this_rank(sysfs: str | None = None) -> dict | None:
     Nothing happens for a single-process run or with DC_CPU_PLACEMENT=0."""
     if not enabled():
         return None
+    try:
+        return _apply_for_this_rank(sysfs)
+    except Exception:  # an unreadable topology or a refused affinity call is never a reason to fail a run
+        return None
+
+
+def _apply_for_this_rank(sysfs: str | None) -> dict | None:
     given = os.environ.get("DC_CPUSET")
     if given:
         info = apply(parse_cpulist(given))

@@ -24,7 +24,7 @@ L = _lib.lib()
 for _ in range(2):
     model.net.forward(d_ids, d_q)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 40)()
+buf = (C.c_ulonglong * 56)()
 L.dc_debug_read_stamps(buf)
 for _ in range(3):
     model.net.forward(d_ids, d_q)
@@ -40,3 +40,13 @@ for e, n in names.items():
             print(f"   clock {tot / rt * 100:.0f} MHz (memtime / memrealtime), wave lifetime {rt / waves / 100:.1f} us")
         print(f"{n:14s} waves {waves:9d}  prologue {pro / waves:8.0f} ({100 * pro / tot:4.1f}%)  loop {loop / waves:8.0f} "
               f"({100 * loop / tot:4.1f}%)  epilogue {epi / waves:8.0f} ({100 * epi / tot:4.1f}%)  cycles/wave")
+
+for r, n in enumerate(("hyena4 consumer", "hyena4 Z (z tiles)", "hyena4 Y (outputs)")):
+    pro, work, wait, waves = (buf[40 + 4 * r + j] for j in range(4))
+    if waves:
+        tot = pro + work + wait
+        print(f"{n:20s} waves {waves:9d}  prologue {pro / waves:8.0f} ({100 * pro / tot:4.1f}%)  working {work / waves:9.0f} "
+              f"({100 * work / tot:4.1f}%)  at the barrier {wait / waves:9.0f} ({100 * wait / tot:4.1f}%)  cycles/wave")
+if buf[40 + 15]:
+    w = buf[40 + 15]
+    print(f"hyena4 Y phases: load-wait + gate {buf[40 + 12] / w:9.0f}  patch-wait {buf[40 + 13] / w:9.0f}  cycles/wave")
