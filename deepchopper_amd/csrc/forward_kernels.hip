@@ -2180,15 +2180,18 @@ int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   DC_REQUIRE(a.kfp && a.kfp_nu == hyena3_units(a.kf_taps), "hyena3 needs the 16-bit filter planes");
   const bool tab = a.tok != nullptr;
   if (tab) DC_REQUIRE(a.tab && a.vocab >= 1 && a.vocab <= 16, "hyena3 table gather needs the layer-0 table and vocab <= 16");
-  // reads <= 1 024 tokens: the warp-specialised form (hyena_ws_kernel.inc); DC_H3_WS=0 keeps hyena3_kernel<32> (A/B, parity)
+  // the warp-specialised form (hyena_ws_kernel.inc) wherever a group's filter window fits its LDS: up to 96 blocks with the
+  // fp16 planes, 64 with the bf16 ones; DC_H3_WS=0 keeps hyena3_kernel (A/B, parity)
   const char* ws_env = getenv("DC_H3_WS");
-  const bool ws = !(ws_env && atoi(ws_env) == 0) && max_P <= 32 && !getenv("DC_H3_CB16");
+  const bool ws_on = !(ws_env && atoi(ws_env) == 0) && !getenv("DC_H3_CB16");
   if (a.split_mode == 1) {
     DC_REQUIRE(a.kfp_f16 && a.ch_inv_scale && a.overflow, "fp16x3 long convolution needs its planes / scales / guard");
-    if (ws) return tab ? launch_hyena4_t<1, true>(st, a, n_groups) : launch_hyena4_t<1, false>(st, a, n_groups);
+    if (ws_on && max_P <= 32 * h4_max_chunks(2))
+      return tab ? launch_hyena4_t<1, true>(st, a, n_groups, max_P) : launch_hyena4_t<1, false>(st, a, n_groups, max_P);
     return tab ? launch_hyena3_t<1, true>(st, a, n_groups, max_P) : launch_hyena3_t<1, false>(st, a, n_groups, max_P);
   }
-  if (ws) return tab ? launch_hyena4_t<0, true>(st, a, n_groups) : launch_hyena4_t<0, false>(st, a, n_groups);
+  if (ws_on && max_P <= 32 * h4_max_chunks(3))
+    return tab ? launch_hyena4_t<0, true>(st, a, n_groups, max_P) : launch_hyena4_t<0, false>(st, a, n_groups, max_P);
   return tab ? launch_hyena3_t<0, true>(st, a, n_groups, max_P) : launch_hyena3_t<0, false>(st, a, n_groups, max_P);
 }
 

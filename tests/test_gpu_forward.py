@@ -491,8 +491,9 @@ def test_layer0_table_gather_is_bit_identical(hip_lib, monkeypatch):
 def test_warp_specialised_long_convolution_is_bit_identical_to_hyena3(hip_lib, monkeypatch, mode, gpw):
     """csrc/hyena_ws_kernel.inc (producer waves build the gated-input tiles and finish the output blocks, consumer waves
     only run MFMAs; a workgroup streams several 32-read groups of its channel) against hyena3_kernel<32> of the same build
+    and, for reads above 1 024 tokens (two or three output chunks per group), hyena3_kernel<16>
     (DC_H3_WS=0): same arithmetic in the same order, so the logits must be BIT-identical -- on ragged batches whose groups
-    differ in length (1 .. 32 blocks per group, groups with empty read slots, reads that end inside a block), on a dense
+    differ in length (1 .. 80 blocks per group, groups with empty read slots, reads that end inside a block), on a dense
     left-padded batch, with the layer-0 token-table gather and without it, and for every groups-per-workgroup setting."""
     from deepchopper_amd import ops
     from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
@@ -502,7 +503,10 @@ def test_warp_specialised_long_convolution_is_bit_identical_to_hyena3(hip_lib, m
     sd = synthetic_state_dict(77)
     rng = np.random.default_rng(77)
     lens = np.concatenate([rng.integers(1, 1025, 150), [1, 2, 3, 4, 5, 31, 32, 33, 64, 65, 992, 993, 1023, 1024] * 2,
-                           np.full(70, 1001)]).astype(np.int32)
+                           np.full(70, 1001),
+                           # groups of two and three output chunks (the 16-block form of hyena3 on the other side)
+                           rng.integers(1025, 2561, 60), [1025, 1056, 1057, 2047, 2048, 2049, 2080, 2081, 2559, 2560] * 2,
+                           np.full(40, 2001)]).astype(np.int32)
     B, stride = len(lens), int(lens.max())
     ids = np.full((B, stride), 4, np.uint8)
     q = np.zeros((B, stride), np.float32)
