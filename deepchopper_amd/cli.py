@@ -241,7 +241,7 @@ def _predict(args, argv: list[str]) -> int:
 
     from . import _lib
     from .model import HUB_NAMES, DeepChopper
-    from .predict import PredictPipeline, write_pt_batch
+    from .predict import PredictPipeline, write_pt_batches
 
     _lib.require_gpu()
     rank = int(os.environ.get("RANK", "0"))
@@ -291,9 +291,22 @@ def _predict(args, argv: list[str]) -> int:
     else:
         os.makedirs(out_dir / "0", exist_ok=True)
         tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w") if args.native else None
+        # the 28 B/token wire format is pickled and written on worker threads (--threads; the reference writes from its one
+        # predict loop, callbacks.py:12-25): a fused launch is ~30 MB in ~85 files, and one thread's torch.save tops out near
+        # 400 MB/s -- 12 k reads/s -- next to a GPU path of 32 k
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = ThreadPoolExecutor(max(1, args.threads)) if not args.no_pt else None
+        pending: list = []
         try:
             # reference mode (-b): left-padded batches whose pad tokens run through the model, int64
             # ids for the .pt wire format; --native: every read at its own length
+            if not args.native:
+                # reference batches (-b reads each, left-padded per batch) share GPU launches: a 12-read batch fills a
+                # fifth of the chip, a fused launch all of it; every batch still gets its own `.pt` file
+                from .fastq import fuse_chunks
+
+                chunks = fuse_chunks(chunks, max_reads=args.max_reads, max_bases=args.max_tokens // 2)  # (padding inflates bases into tokens)
             for res in pipe.predict_stream(chunks, reference_padding=not args.native, ids_i64=not args.no_pt,
                                            want_labels=not args.no_pt):
                 if tsv is not None:
@@ -301,11 +314,18 @@ def _predict(args, argv: list[str]) -> int:
                     tsv.write("".join(
                         f"{name}\t{int(lens[r])}\t" + ",".join(f"{s}:{e}" for s, e in iv[r, : int(niv[r])].tolist()) + "\n"
                         for r, name in enumerate(res["names"])))
-                if not args.no_pt:
-                    write_pt_batch(str(out_dir / "0" / f"{rank}_{n_batches}.pt"), res["device"], res["names"])
-                n_batches += 1
+                if not args.no_pt:  # one reference batch = one file, as CustomWriter writes them
+                    n_batches += write_pt_batches(str(out_dir / "0"), rank, n_batches, res["device"], res["names"], pool, pending)
+                    while len(pending) > 4 * max(1, args.threads):  # bound the host copies waiting to be written
+                        pending.pop(0).result()
+                else:
+                    n_batches += len(res.get("sub_sizes") or [0])
                 n_reads += len(res["names"])
+            for f in pending:
+                f.result()  # (a failed write raises here)
         finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
             if tsv is not None:
                 tsv.close()
     if n_reads == 0 and world == 1:

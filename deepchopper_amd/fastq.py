@@ -32,11 +32,12 @@ class FastqChunk:
     or -- from a reader opened with `full_header=True` -- the whole definition line, with `_name_len[r]`
     giving the length of the name part."""
 
-    __slots__ = ("n", "seq", "qual", "offsets", "_names", "_name_offsets", "_name_len")
+    __slots__ = ("n", "seq", "qual", "offsets", "_names", "_name_offsets", "_name_len", "sub_sizes")
 
-    def __init__(self, n, seq, qual, offsets, names, name_offsets, name_len=None):
+    def __init__(self, n, seq, qual, offsets, names, name_offsets, name_len=None, sub_sizes=None):
         self.n, self.seq, self.qual, self.offsets = n, seq, qual, offsets
         self._names, self._name_offsets, self._name_len = names, name_offsets, name_len
+        self.sub_sizes = sub_sizes  # fused reference batches (`fuse_chunks`): reads per original chunk, in order
 
     @property
     def lengths(self) -> np.ndarray:
@@ -56,6 +57,46 @@ class FastqChunk:
         s, q, o = self.seq.tobytes(), self.qual.tobytes(), self.offsets
         for i, name in enumerate(self.names()):
             yield name, s[o[i]: o[i + 1]], q[o[i]: o[i + 1]]
+
+
+def fuse_chunks(chunks, max_reads: int, max_bases: int):
+    """Concatenate consecutive chunks (copies) into larger ones of at most `max_reads` reads / `max_bases` bases, remembering
+    the original sizes in `sub_sizes`.  For the reference-compatible `predict -b 12`: every reader chunk is one batch of the
+    reference's DataLoader; fused, many of them share ONE GPU launch while each keeps its own left padding (and its own
+    `.pt` file).  A chunk that alone exceeds the limits is passed through on its own."""
+    pend: list[FastqChunk] = []
+    n = nb = 0
+
+    def flush():
+        nonlocal pend, n, nb
+        if not pend:
+            return None
+        offs = np.zeros(n + 1, np.int64)
+        noffs = np.zeros(n + 1, np.int64)
+        r = b = hb = 0
+        for c in pend:
+            offs[r + 1: r + c.n + 1] = c.offsets[1: c.n + 1] + b
+            noffs[r + 1: r + c.n + 1] = c._name_offsets[1: c.n + 1] + hb
+            r, b, hb = r + c.n, b + int(c.offsets[c.n]), hb + int(c._name_offsets[c.n])
+        seq = np.concatenate([c.seq[: int(c.offsets[c.n])] for c in pend])
+        qual = np.concatenate([c.qual[: int(c.offsets[c.n])] for c in pend])
+        names = np.concatenate([c._names[: int(c._name_offsets[c.n])] for c in pend])
+        nlen = None if pend[0]._name_len is None else np.concatenate([c._name_len[: c.n] for c in pend])
+        out = FastqChunk(n, seq, qual, offs, names, noffs, nlen, sub_sizes=[c.n for c in pend])
+        pend, n, nb = [], 0, 0
+        return out
+
+    for c in chunks:
+        cb = int(c.offsets[c.n])
+        if pend and (n + c.n > max_reads or nb + cb > max_bases):
+            yield flush()
+        pend.append(FastqChunk(c.n, c.seq[:cb].copy(), c.qual[:cb].copy(), c.offsets[: c.n + 1].copy(),
+                               c._names[: int(c._name_offsets[c.n])].copy(), c._name_offsets[: c.n + 1].copy(),
+                               None if c._name_len is None else c._name_len[: c.n].copy()))
+        n, nb = n + c.n, nb + cb
+    last = flush()
+    if last is not None:
+        yield last
 
 
 def decode_names(names: np.ndarray, name_offsets: np.ndarray, name_len: np.ndarray | None, n: int) -> list[str]:

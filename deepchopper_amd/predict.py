@@ -81,13 +81,19 @@ class PredictPipeline:
     # ---- whole hot path on one device batch ---------------------------------------------
     def run_device_batch(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, lens_host: np.ndarray,
                          *, reference_padding: bool = False, want_labels: bool = True, ids_i64: bool = False,
-                         staging: _Pinned | None = None):
+                         staging: _Pinned | None = None, sub_sizes: list[int] | None = None):
         """seq/qual: concatenated raw bytes on the device; offsets int64[n+1] on the device;
         lens_host: read lengths (host copy, known from parsing).
 
         reference_padding=False (native): every read is run at its own length (== the reference
         at --batch-size 1).  reference_padding=True: the batch is left-padded to its longest read
         and the pad tokens run through the model exactly as in the reference.
+
+        sub_sizes (with reference_padding): the batch is SEVERAL reference batches fused into one launch
+        (`fastq.fuse_chunks`): rows sub_sizes[0] | sub_sizes[1] | ...; every sub-batch keeps its own left padding -- a
+        row of sub-batch i runs through the model with the pad tokens that make it as long as the longest read of
+        sub-batch i, exactly what the reference's collator gives it -- so the logits are those of separate launches
+        (`res["sub_cols"][i]` = the column its rows start at; `write_pt_batch(..., rows, col0)` cuts a sub-batch out).
 
         Every launch is asynchronous: the per-read index arrays go up in one copy BEFORE the forward is
         launched (from `staging`, pinned, when given), and nothing is read back here."""
@@ -113,7 +119,20 @@ class PredictPipeline:
 
         tok = self.tokenize(seq, qual, offsets, max_len, pad_left=True, ids_i64=ids_i64, want_labels=want_labels)
         assert tok["input_ids"].shape[1] == row_stride
-        if reference_padding or bool(np.all(ntok == row_stride)):
+        sub_cols = None
+        if reference_padding and sub_sizes is not None and len(sub_sizes) > 1:
+            # tokens of a row as the reference's collator pads it: up to the longest read of ITS sub-batch
+            sub_tok = np.empty(n, np.int32)
+            sub_cols = []
+            r0 = 0
+            for k in sub_sizes:
+                lb = int(ntok[r0: r0 + k].max())
+                sub_tok[r0: r0 + k] = lb
+                sub_cols.append(row_stride - lb)
+                r0 += k
+            assert r0 == n, "sub_sizes must add up to the batch"
+            logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], (row_stride - sub_tok).astype(np.int32), sub_tok)
+        elif reference_padding or bool(np.all(ntok == row_stride)):
             logits = self.model.net.forward(tok["input_ids"], tok["input_quals"])
         else:
             logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
@@ -123,7 +142,8 @@ class PredictPipeline:
                                               out_offsets=out_offsets if want_labels else None, total=total)
         if not want_labels:
             sm["offsets"] = out_offsets
-        return {"tok": tok, "logits": logits, "smooth": sm, "first": first, "n_tokens": ntok, "offsets_host": oo.copy()}
+        return {"tok": tok, "logits": logits, "smooth": sm, "first": first, "n_tokens": ntok, "offsets_host": oo.copy(),
+                "sub_sizes": sub_sizes, "sub_cols": sub_cols}
 
     def run_checked(self, seq, qual, offsets, lens_host, **kw):
         """run_device_batch with the fp16x3 range guard consulted (synchronises): a batch in which an activation
@@ -244,6 +264,7 @@ class PredictPipeline:
                     slot.header_offsets = np.array(c._name_offsets, copy=True)
                     slot.name_len = None if c._name_len is None else np.array(c._name_len, copy=True)
                     slot.lens = np.diff(slot.offs)
+                    slot.sub_sizes = getattr(c, "sub_sizes", None)
                     while not stop.is_set():
                         try:
                             q.put(slot, timeout=0.1)
@@ -270,7 +291,8 @@ class PredictPipeline:
                 net.set_overflow_target(counter)
             try:
                 res = self.run_device_batch(d_seq, d_qual, d_offs, slot.lens, reference_padding=reference_padding,
-                                            want_labels=want_labels, ids_i64=ids_i64, staging=slot.pin)
+                                            want_labels=want_labels, ids_i64=ids_i64, staging=slot.pin,
+                                            sub_sizes=slot.sub_sizes if reference_padding else None)
             finally:
                 if guard:
                     net.set_overflow_target(None)
@@ -298,7 +320,8 @@ class PredictPipeline:
             b["copied"].synchronize()
             if int(host["guard"][0]) > 0:  # this batch (and only this one) left the fp16 range: redo it in bf16x6
                 res = self._rerun_bf16x6(*b["d_in"], slot.lens, reference_padding=reference_padding,
-                                         want_labels=want_labels, ids_i64=ids_i64)
+                                         want_labels=want_labels, ids_i64=ids_i64,
+                                         sub_sizes=slot.sub_sizes if reference_padding else None)
                 sm = res["smooth"]
                 host = {"status": res["tok"]["status"].cpu().numpy(), "intervals": sm["intervals"].cpu().numpy(),
                         "n_intervals": sm["n_intervals"].cpu().numpy(), "keep": sm["keep"].cpu().numpy(),
@@ -317,6 +340,7 @@ class PredictPipeline:
                 "intervals": own(host["intervals"]), "n_intervals": own(host["n_intervals"]),
                 "keep": own(host["keep"]), "n_keep": own(host["n_keep"]), "truncated": (status & 1) != 0,
                 "range_guard_rerun": bool(res.get("range_guard_rerun", False)),
+                "sub_sizes": res.get("sub_sizes"), "sub_cols": res.get("sub_cols"),
                 "device": res,  # device-resident tensors of the batch (logits, token matrices) for write_pt_batch
             }
             if want_labels:
@@ -348,17 +372,60 @@ class PredictPipeline:
 _NP = {torch.int8: np.int8, torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64, torch.float32: np.float32}
 
 
-def write_pt_batch(path: str, res: dict, ids: list[str]) -> None:
+def write_pt_batch(path: str, res: dict, ids: list[str], rows: slice | None = None, col0: int = 0) -> None:
     """CustomWriter.write_on_batch_end (callbacks.py:12-25): the reference's predict -> chop wire
-    format, `{prediction f32[B,L,2], target i64[B,L], seq i64[B,L], qual f32[B,L], id i64[B,256]}`."""
+    format, `{prediction f32[B,L,2], target i64[B,L], seq i64[B,L], qual f32[B,L], id i64[B,256]}`.
+    `rows` / `col0` cut one reference batch out of a fused launch (`run_device_batch(..., sub_sizes=...)`): its rows, from the
+    column where its own left padding starts; `ids` are the names of those rows."""
     tok = res["tok"]
-    truncated = (tok["status"].cpu().numpy() & 1) != 0
+    rows = slice(None) if rows is None else rows
+    truncated = (tok["status"][rows].cpu().numpy() & 1) != 0
     idm = np.stack([encode_ids_int8(i, bool(t)) for i, t in zip(ids, truncated)]).astype(np.int64)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save({
-        "prediction": res["logits"].cpu(),
-        "target": tok["labels"].cpu().to(torch.int64),
-        "seq": tok["input_ids"].cpu().to(torch.int64),
-        "qual": tok["input_quals"].cpu(),
+        "prediction": res["logits"][rows, col0:].contiguous().cpu(),
+        "target": tok["labels"][rows, col0:].contiguous().cpu().to(torch.int64),
+        "seq": tok["input_ids"][rows, col0:].contiguous().cpu().to(torch.int64),
+        "qual": tok["input_quals"][rows, col0:].contiguous().cpu(),
         "id": torch.from_numpy(idm),
     }, path)
+
+
+def write_pt_batches(dir_path: str, rank: int, first_index: int, res: dict, ids: list[str], pool=None, pending: list | None = None) -> int:
+    """Every reference batch of a (possibly fused) launch as its own `{rank}_{index}.pt` (CustomWriter's naming,
+    callbacks.py:25).  The device tensors come to the host ONCE per launch; a batch is cut out of the host copies (its
+    rows, from the column where its own left padding starts) and copied, so a file holds its own storage only.
+    With `pool` (a ThreadPoolExecutor) the pickling / writing of the files runs on its threads (futures appended to
+    `pending`; the caller waits for them and bounds how many are in flight).  Returns the number of files."""
+    tok = res["tok"]
+    subs = res.get("sub_sizes") or [len(ids)]
+    cols = res.get("sub_cols") or [0] * len(subs)
+    host = {"prediction": res["logits"].cpu(), "target": tok["labels"].cpu(), "seq": tok["input_ids"].cpu(),
+            "qual": tok["input_quals"].cpu()}
+    truncated = (tok["status"].cpu().numpy() & 1) != 0
+    os.makedirs(dir_path, exist_ok=True)
+
+    def save(i: int, r0: int, k: int, c0: int) -> None:
+        idm = np.stack([encode_ids_int8(n, bool(t)) for n, t in zip(ids[r0: r0 + k], truncated[r0: r0 + k])]).astype(np.int64)
+        torch.save({
+            "prediction": host["prediction"][r0: r0 + k, c0:].clone(),
+            "target": host["target"][r0: r0 + k, c0:].to(torch.int64, copy=True),  # (copies: a view would drag the fused
+            "seq": host["seq"][r0: r0 + k, c0:].to(torch.int64, copy=True),        #  launch's whole storage into the file)
+            "qual": host["qual"][r0: r0 + k, c0:].clone(),
+            "id": torch.from_numpy(idm),
+        }, os.path.join(dir_path, f"{rank}_{first_index + i}.pt"))
+
+    def save_range(lo: int, hi: int, starts: list[int]) -> None:
+        for i in range(lo, hi):
+            save(i, starts[i], subs[i], cols[i])
+
+    starts = [0] * len(subs)
+    for i in range(1, len(subs)):
+        starts[i] = starts[i - 1] + subs[i - 1]
+    if pool is None:
+        save_range(0, len(subs), starts)
+    else:
+        step = max(1, -(-len(subs) // 4))  # a launch's files as up to four jobs
+        for lo in range(0, len(subs), step):
+            pending.append(pool.submit(save_range, lo, min(len(subs), lo + step), starts))
+    return len(subs)

@@ -288,3 +288,26 @@ def test_rank_chunks_cover_every_read_once(tmp_path, container):
     assert len(list(limit_batches(rank_chunks(p, 0, 1, 50, 20_000), 3))) == 3
     sizes = [c.n for c in rank_chunks(p, 0, 1, 50, 20_000)]
     assert max(sizes) <= 50 and sum(sizes) == 700
+
+
+def test_fuse_chunks_keeps_every_read_and_the_batch_boundaries(tmp_path):
+    """fastq.fuse_chunks (the reference-compatible `predict -b 12` shares GPU launches between reference batches): the fused
+    chunks hold the same reads in the same order, `sub_sizes` are the original chunk sizes, and the limits are honoured."""
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader, fuse_chunks
+
+    seqs, quals, ids = synth.synth_reads_mixed(103, 40, 900, seed=12)
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(synth.fastq_text([i.encode() + b" ch=%d" % k for k, i in enumerate(ids)], seqs, quals))
+    for full in (False, True):
+        with FastqReader(str(fq), full_header=full) as rd:
+            fused = list(fuse_chunks(rd.chunks(12, 1 << 30), max_reads=60, max_bases=20000))
+        assert sum(c.n for c in fused) == 103 and len(fused) >= 2
+        sizes = [k for c in fused for k in c.sub_sizes]
+        assert sizes == [12] * 8 + [7] and all(sum(c.sub_sizes) == c.n for c in fused)
+        assert all(c.n <= 60 and (int(c.offsets[c.n]) <= 20000 or len(c.sub_sizes) == 1) for c in fused)
+        got = [r for c in fused for r in c.records()]
+        assert [g[0] for g in got] == ids and [g[1] for g in got] == seqs and [g[2] for g in got] == quals
+    with FastqReader(str(fq)) as rd:  # a chunk larger than the limits passes on its own
+        big = list(fuse_chunks(rd.chunks(50, 1 << 30), max_reads=10, max_bases=100))
+    assert [c.sub_sizes for c in big] == [[50], [50], [3]]

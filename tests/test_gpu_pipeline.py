@@ -629,3 +629,52 @@ def test_results_do_not_depend_on_a_handles_history_or_stream(env, tmp_path):
     assert np.array_equal(valid_logits(r2, long_[3]), valid_logits(seasoned.run_device_batch(*long_), long_[3]))
     for k in ("pred", "smooth", "intervals", "n_intervals", "keep", "n_keep"):
         assert torch.equal(r1["smooth"][k], fresh.run_device_batch(*short)["smooth"][k]), k
+
+
+def test_fused_reference_batches_write_the_files_of_separate_launches(env, tmp_path):
+    """`deepchopper predict -b 12` (the reference's default: left-padded batches of 12, one `.pt` per batch,
+    deepchopper/cli.py:70, models/callbacks.py:12-25) shares GPU launches between reference batches (`fastq.fuse_chunks`): every
+    batch keeps ITS OWN left padding -- its pad tokens run through the model as the reference's collator lays them out
+    (tokenizer.py:71-87) -- so the files must be those of one launch per batch: same names, shapes, token / label /
+    quality / id tensors bit for bit, logits to fp32 rounding (another batch composition reorders nothing inside a row, but the
+    long-convolution groups differ), and against the batched oracle within the parity tolerance."""
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader, fuse_chunks
+    from deepchopper_amd.predict import write_pt_batch
+
+    seqs, quals, ids = synth.synth_reads_mixed(67, 60, 1400, seed=21)  # batches of 12 with very different paddings; 67 = 5 x 12 + 7
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+
+    def run(fused: bool, out):
+        n = 0
+        with FastqReader(str(fq)) as rd:
+            chunks = rd.chunks(12, 1 << 30)
+            if fused:
+                chunks = fuse_chunks(chunks, max_reads=40, max_bases=1 << 30)  # 3 + 3 batches per launch
+            for res in pipe.predict_stream(chunks, reference_padding=True, ids_i64=True):
+                subs = res["sub_sizes"] or [len(res["names"])]
+                cols = res["sub_cols"] or [0] * len(subs)
+                assert fused == (len(subs) > 1) or len(res["names"]) <= 12
+                r0 = 0
+                for k, c0 in zip(subs, cols):
+                    write_pt_batch(str(out / f"0_{n}.pt"), res["device"], res["names"][r0: r0 + k], rows=slice(r0, r0 + k), col0=c0)
+                    n += 1
+                    r0 += k
+        return n
+
+    a, b = tmp_path / "separate", tmp_path / "fused"
+    assert run(False, a) == run(True, b) == 6
+    for i in range(6):
+        x = torch.load(a / f"0_{i}.pt", weights_only=True)
+        y = torch.load(b / f"0_{i}.pt", weights_only=True)
+        assert x["prediction"].shape == y["prediction"].shape and x["prediction"].shape[0] == (12 if i < 5 else 7)
+        for key in ("target", "seq", "qual", "id"):
+            assert torch.equal(x[key], y[key]), (i, key)
+        assert float((x["prediction"] - y["prediction"]).abs().max()) < 2e-5
+        assert (y["seq"][:, 0] != 4).any()  # cut at the batch's own padding: its longest read starts in column 0
+    # ... and the fused files against the oracle run batch by batch (the reference at -b 12)
+    ref = _oracle_reads(sd, ids[:12], seqs[:12], quals[:12], batch=12)
+    y = torch.load(b / "0_0.pt", weights_only=True)
+    assert np.abs(y["prediction"].numpy() - ref[ids[0]][1]).max() < 2e-4

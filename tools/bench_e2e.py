@@ -188,11 +188,16 @@ def ref_batch_bench(args):
     pipe = PredictPipeline(DeepChopper.synthetic(seed=42))
     out = {"mode": f"reference batches of {args.ref_batch} reads (left-padded, int64 ids, labels + intervals to the host)",
            "reads": args.reads, "bp": args.bp}
-    for name, ser in (("warmup", False), ("pipelined", False), ("serialised", True)):
+    from deepchopper_amd.fastq import fuse_chunks
+
+    for name, ser in (("warmup", False), ("pipelined", False), ("serialised", True), ("fused", False)):
         t0 = time.time()
         n = 0
         with FastqReader(path) as rd:
-            for res in pipe.predict_stream(rd.chunks(args.ref_batch, 1 << 26), reference_padding=True, ids_i64=True, serialize=ser):
+            chunks = rd.chunks(args.ref_batch, 1 << 26)
+            if name == "fused":  # what `deepchopper predict -b 12` does since round 4: reference batches share launches
+                chunks = fuse_chunks(chunks, max_reads=8192, max_bases=1_000_000)
+            for res in pipe.predict_stream(chunks, reference_padding=True, ids_i64=True, serialize=ser):
                 n += len(res["names"])
                 if name == "warmup" and n >= 50 * args.ref_batch:
                     break
