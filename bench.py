@@ -232,8 +232,9 @@ def main():
                     "mode (bf16x6) -> `value_bf16x6` (0 = skip)")
     ap.add_argument("--e2e-reads", type=int, default=1_000_000, help="FASTQ-inclusive leg through predict_stream -> `file_e2e`: "
                     "configs[1]'s stated size, ~31 s sustained (N = 1 only; 0 = skip)")
-    ap.add_argument("--legs", default="c1,c3,c4,c5", help="per-config legs -> `configs.*` (N = 1 only; '' = none): c1 = 512 bp, "
-                    "c3 = 2 kb one-GPU slice, c4 = mixed 100 bp - 10 kb file, c5 = .fastq.gz -> chopped BGZF")
+    ap.add_argument("--legs", default="c1,c3,c4,c5,ref", help="per-config legs -> `configs.*` (N = 1 only; '' = none): c1 = 512 bp, "
+                    "c3 = 2 kb one-GPU slice, c4 = mixed 100 bp - 10 kb file, c5 = .fastq.gz -> chopped BGZF, ref = the reference's "
+                    "default batching (-b 12, left-padded batches)")
     ap.add_argument("--c4-reads", type=int, default=40_000)
     ap.add_argument("--c5-reads", type=int, default=300_000)
     args = ap.parse_args()
@@ -468,6 +469,8 @@ def main():
                 configs["c4_mixed"] = leg(bench_legs.mixed_leg, pipe, sd, args.c4_reads)
             if "c5" in legs:
                 configs["c5_gz_chop"] = leg(bench_legs.gz_chop_leg, args.c5_reads, threads=4)
+            if "ref" in legs:
+                configs["reference_b12"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000)
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",

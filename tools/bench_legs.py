@@ -7,6 +7,8 @@ the CPU oracle on a bounded sample (the oracle is the checker here, never the th
     configs.c4_mixed            configs[3]  log-uniform 100 bp - 10 kb FASTQ file -> predict_stream (token-budget batches) -> intervals
     configs.c5_gz_chop          configs[4]  nanopore-like .fastq.gz -> fused predict -> chop -> BGZF (-t 4), adapters planted
     file_e2e                    configs[1]  1 000 000 x 1 kb reads, FASTQ file -> labels + intervals, first vs last 100 k reads
+    configs.reference_b12       the reference's default batching (`predict -b 12`: left-padded batches of 12, pad tokens through
+                                the model), reference batches fused into shared launches, FASTQ file -> logits / labels / intervals
 """
 from __future__ import annotations
 
@@ -312,4 +314,70 @@ def file_e2e_leg(pipe, sd, n_reads: int, read_len: int, batch: int, check_reads:
         exp = oracle_reads(sd, first["names"], first["seq"], first["qual"])
         out["check"] = f1_check(exp, first["got"])
         out["check"]["reads_counted"] = n == n_reads
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the reference's default batching (-b 12)
+# ------------------------------------------------------------------------------------------------------------
+def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000) -> dict:
+    """FASTQ file -> batches of 12 as the reference's DataLoader forms them (deepchopper/cli.py:70) -> left-padded per batch,
+    pad tokens through the model -> logits + labels + intervals on the host; reference batches share GPU
+    launches (`fastq.fuse_chunks`), each with its own padding.  Mixed lengths around `read_len` so that the padding is real.
+    Check: the first batch against the oracle run on that batch of 12 (logits <= 1e-3, labels, intervals)."""
+    import torch
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader, fuse_chunks
+
+    seqs, quals, ids = synth.synth_reads_mixed(n_reads, read_len // 2, read_len + read_len // 2, seed=77)
+    bases = sum(len(x) for x in seqs)
+    tmp = tempfile.mkdtemp(prefix="dc_ref_")
+    path = os.path.join(tmp, "reads.fq")
+    try:
+        with open(path, "wb") as fh:
+            fh.write(synth.to_fastq(seqs, quals, ids))
+
+        def run(limit=None):
+            n = 0
+            first = None
+            with FastqReader(path) as rd:
+                for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 1_000_000), reference_padding=True, ids_i64=True):
+                    if first is None:
+                        k, c0 = res["sub_sizes"][0], res["sub_cols"][0]
+                        o = res["offsets"]
+                        first = {"logits": res["device"]["logits"][:k, c0:].cpu().numpy(), "names": res["names"][:k],
+                                 "got": {res["names"][r]: (np.array(res["pred"][o[r]: o[r + 1]]),
+                                                           res["intervals"][r, : res["n_intervals"][r]].tolist()) for r in range(k)}}
+                    n += len(res["names"])
+                    if limit and n >= limit:
+                        break
+            return n, first
+
+        run(limit=3000)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n, first = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {"workload": "the reference's default batching: FASTQ file -> batches of 12 (left-padded per batch, pad tokens through the "
+                       "model) -> logits + labels + intervals on the host; batches fused into shared launches, each with its own padding",
+           "value": round(n / dt, 1), "unit": "reads/s", "Mbases_per_s": round(bases / dt / 1e6, 2), "reads": n, "seconds": round(dt, 3),
+           "mean_bp": round(bases / n_reads, 1)}
+    from oracle import dc_oracle as o
+    from oracle import forward_ref as fr
+
+    feats = []
+    for i in range(12):
+        rec = o.parse_fastq_record(ids[i], seqs[i].decode(), quals[i].decode())
+        feats.append(o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"]))
+    b = o.collate(feats)
+    ref = fr.forward(sd, b["input_ids"], b["input_quals"]).numpy()
+    preds = o.load_predicts_from_batch({"prediction": ref, "target": b["labels"], "seq": b["input_ids"], "id": b["id"]})
+    exp = {rid: (p.prediction, p.smooth_label(21), p.smooth_and_select_intervals(21, 13, 20)) for rid, p in preds.items()}
+    out["check"] = f1_check(exp, first["got"])
+    out["check"]["max_abs_dlogit_vs_batched_oracle"] = float(np.abs(first["logits"] - ref).max())
+    out["check"]["reads_counted"] = n == n_reads
     return out
