@@ -471,6 +471,7 @@ def main():
                 configs["c5_gz_chop"] = leg(bench_legs.gz_chop_leg, args.c5_reads, threads=4)
             if "ref" in legs:
                 configs["reference_b12"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000)
+                configs["reference_b12_nanopore"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000, mix="nanopore")
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",

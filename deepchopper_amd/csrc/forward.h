@@ -93,6 +93,13 @@ struct HyenaArgs {
   const unsigned char* tok;       // [Tp] token id per packed slot, 255 = no token; nullptr = read `u`
   const float* tab;               // [vocab][3D] in_proj(LayerNorm(emb[id])) (x0 | x1 | v)
   int vocab;                      // <= 16
+  // Shared [PAD] prefix (dc_forward_shared_prefix; nullptr = every read owns all of its positions).  A row of a left-padded
+  // reference batch is `[PAD] x p ++ read`; HyenaDNA is causal, so what the model holds over the pad run does not depend on
+  // the row and ONE all-[PAD] row per launch carries it.  A read's positions t < pv[r] (a multiple of 4: the 16-byte accesses
+  // below never straddle) live in that row's slots, padoff[r] + t; positions t >= pv[r] in its own slots, toff[r] + t
+  // (toff[r] = first own slot - pv[r]).  Only own positions are stored.
+  const int32_t* pv;              // [n_reads] positions in front of the read's own slots
+  const int32_t* padoff;          // [n_reads] slot of the shared row that stands for the read's position 0
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
@@ -124,20 +131,25 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
                          unsigned short* kfp_f16, const float* ch_scale);
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                 int64_t Tp, float* x, float* qpad);
+                 int64_t Tp, float* x, float* qpad, int pad_id);  // src_base[r] < 0: a shared [PAD] row (token pad_id, quality 0)
 int launch_load_hidden(hipStream_t st, const float* hidden, const float* quals, int D, const int32_t* blk_read,
                        const int32_t* toff, const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x,
                        float* qpad);
 int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd);
 int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
                        const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                       float* logits);
+                       float* logits, float* padlog);  // src_base[r] < 0: logits of a shared [PAD] row -> padlog + (-1 - src_base[r])
 int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
                     const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
                     const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad,
-                    unsigned char* tok);  // u == nullptr: only x, qpad and the packed token ids `tok` are written
+                    unsigned char* tok, int pad_id);  // u == nullptr: only x, qpad and the packed token ids `tok` are written
 int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
                     const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                    float* logits);
+                    float* logits, float* padlog);
+// dc_forward_shared_prefix: row j of the fill list gets logits[fill_dst[j] + i] = padlog[fill_src[j] + i], i < fill_n[j]; `bad` counts
+// wavefronts that met a position not holding (pad_id, quality 0)
+int launch_fill_pad_logits(hipStream_t st, const void* ids, int ids_i64, const float* quals, int n_rows, int max_run,
+                           const int64_t* fill_dst, const int32_t* fill_n, const int32_t* fill_src, const float* padlog,
+                           int pad_id, float* logits, int* bad);
 
 }  // namespace dc

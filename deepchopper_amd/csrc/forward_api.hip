@@ -85,10 +85,21 @@ struct dc_model {
   size_t pinned_bytes = 0;
   hipEvent_t staging_done = nullptr;
   bool staging_pending = false;
-  // device views into idx
+  // device views into idx.  "Units" = the caller's reads, then the shared [PAD] rows of a dc_forward_shared_prefix launch.
+  // Slot map (embed / head scatter): unit u owns slots [d_toff[u], + ceil4(d_ntok[u])), its tokens come from d_src_base[u]
+  // (< 0: a shared [PAD] row -- constant tokens in, logits out to padlog + (-1 - d_src_base[u])).  Long convolution: unit u
+  // is a sequence of d_cntok[u] positions (d_nblk[u] 32-token blocks); positions < d_pv[u] live at slot d_padoff[u] + t, the
+  // others at d_ctoff[u] + t (d_ctoff = d_toff - d_pv).  Without shared prefixes the two views coincide.
   int32_t *d_blk_read = nullptr, *d_toff = nullptr, *d_ntok = nullptr, *d_nblk = nullptr, *d_grp_reads = nullptr,
           *d_grp_P = nullptr;
+  int32_t *d_ctoff = nullptr, *d_cntok = nullptr, *d_pv = nullptr, *d_padoff = nullptr;
   int64_t* d_src_base = nullptr;
+  int64_t* d_fill_dst = nullptr;    // [n_reads] dense position of a row's first pad column
+  int32_t *d_fill_n = nullptr, *d_fill_src = nullptr;  // [n_reads] pad columns of the row; position 0 of its shared row in padlog
+  bool shared_prefix = false;       // the cached geometry has shared [PAD] rows
+  int n_fill_rows = 0, pad_id = 0;
+  DevBuf padlog;                    // float2 per position of the shared [PAD] rows: their logits
+  int* d_prefix_bad = nullptr;      // tokens inside a declared pad prefix that were not ([PAD], quality 0)
   int64_t Tp = 0;
   int n_groups = 0, max_P = 0, min_P = 0;
 
@@ -443,59 +454,116 @@ int run_gemm(dc_model* m, hipStream_t st, const char* name, const WRef& w, const
 }
 
 // Build (or reuse) the packed-layout index arrays for a batch geometry.
+// h_npad (nullable): read r is `[PAD] x h_npad[r]` followed by its own tokens (dc_forward_shared_prefix); the pad runs are not
+// laid out per read -- one all-[PAD] row per long-convolution class carries them (see dc_model: "units").
 int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride, const int32_t* h_first,
-                   const int32_t* h_ntok) {
+                   const int32_t* h_ntok, const int32_t* h_npad = nullptr, int pad_id = 0) {
   // geometry key
   std::vector<int32_t> key;
-  key.reserve(2 * (size_t)n_reads + 4);
+  key.reserve(3 * (size_t)n_reads + 6);
   key.push_back(n_reads);
   key.push_back((int32_t)(row_stride & 0x7fffffff));
   key.push_back((int32_t)(row_stride >> 31));
   key.push_back(m->fft_min_tokens);
+  key.push_back(h_npad ? 1 + pad_id : 0);
   key.insert(key.end(), h_first, h_first + n_reads);
   key.insert(key.end(), h_ntok, h_ntok + n_reads);
+  if (h_npad) key.insert(key.end(), h_npad, h_npad + n_reads);
   if (key == m->h_geom && m->Tp > 0) return DC_OK;
 
-  // Packed layout: a read starts at a multiple of 4 token slots (16-byte aligned fp32 rows for the float4 / 8-byte
-  // accesses of the long-convolution kernels) and owns ceil4(ntok) slots.  (Rounds 1-2 gave every read whole 32-token
+  // long-convolution class of a sequence of nt positions: 0 = block-Toeplitz MFMA, 1 + b = FFT of 2^(10 + b) complex points.
+  // Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by transform size: up to 2^14
+  // tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form.
+  auto conv_class = [&](int nt) -> int {
+    if (nt > m->fft_min_tokens && nt <= (1 << 15) + 1) {
+      int logm = 10;
+      while ((1 << logm) < nt && logm < 15) ++logm;  // 2^15 + 1 tokens still fit the 2^15 form (one tap added by hand)
+      return 1 + logm - 10;
+    }
+    return 0;
+  };
+
+  // Shared [PAD] rows: one per long-convolution class that holds reads with a pad run, as long as the longest run (rounded
+  // down to a multiple of 4: a read owns the last <= 3 pads in front of its first base, so that the 16-byte accesses of the
+  // long-convolution kernels never straddle the two sources).  A row per CLASS because a read's pad positions must see what
+  // they would have seen inside the read's own sequence: the block-Toeplitz forms are exactly causal and bit-identical to
+  // one another, so one row serves them all bit for bit; an FFT form's result depends (in the last bits) on the transform.
+  int pad_len[7] = {0, 0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> pv(n_reads, 0);
+  int n_fill = 0;
+  for (int r = 0; r < n_reads; ++r) {
+    DC_REQUIRE(h_ntok[r] >= 1, "every read needs at least one token");
+    DC_REQUIRE(h_first[r] >= 0 && (int64_t)h_first[r] + h_ntok[r] <= row_stride, "read exceeds its row");
+    if (!h_npad) continue;
+    DC_REQUIRE(h_npad[r] >= 0 && h_npad[r] < h_ntok[r], "a read's pad run must be shorter than the read");
+    pv[r] = h_npad[r] & ~3;
+    n_fill += pv[r] > 0;
+    const int k = conv_class(h_ntok[r]);
+    pad_len[k] = std::max(pad_len[k], (int)pv[r]);
+  }
+  int pad_unit[7], n_units = n_reads;
+  int64_t padlog_len = 0;
+  int32_t padlog_off[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 7; ++k) {
+    pad_unit[k] = -1;
+    if (pad_len[k] > 0) {
+      pad_unit[k] = n_units++;
+      padlog_off[k] = (int32_t)padlog_len;
+      padlog_len += pad_len[k];
+    }
+  }
+  const bool sp = n_units > n_reads;
+
+  // Packed layout: a unit starts at a multiple of 4 token slots (16-byte aligned fp32 rows for the float4 / 8-byte
+  // accesses of the long-convolution kernels) and owns ceil4(own tokens) slots.  (Rounds 1-2 gave every read whole 32-token
   // blocks: 1 001 tokens took 1 024 slots, 2.2 % of every GEMM's work; 513 tokens 544, 6 %.)  The long-convolution
   // kernels still walk a read in 32-token blocks: the tail of its last block overlaps the next read's slots, which they
   // may READ (causal: a later position never reaches an earlier output) but must not write -- their stores are masked
   // by the read's slot count.  32 slots of slack behind the last read keep those reads inside the buffers.
-  std::vector<int32_t> nblk(n_reads), toff(n_reads);
+  std::vector<int32_t> nblk(n_units), toff(n_units), nown(n_units), ctoff(n_units), cntok(n_units), upv(n_units, 0), padoff(n_units, 0);
+  std::vector<int32_t> ucls(n_units);
+  std::vector<int64_t> src_base(n_units);
   int64_t slots = 0;
   int maxP = 0, minP = 1 << 30;
-  for (int r = 0; r < n_reads; ++r) {
-    DC_REQUIRE(h_ntok[r] >= 1, "every read needs at least one token");
-    DC_REQUIRE(h_first[r] >= 0 && (int64_t)h_first[r] + h_ntok[r] <= row_stride, "read exceeds its row");
-    nblk[r] = (h_ntok[r] + 31) / 32;
+  for (int u = 0; u < n_units; ++u) {
+    if (u < n_reads) {
+      upv[u] = pv[u];
+      cntok[u] = h_ntok[u];
+      nown[u] = h_ntok[u] - pv[u];
+      src_base[u] = (int64_t)u * row_stride + h_first[u] + pv[u];
+      ucls[u] = conv_class(h_ntok[u]);
+    } else {
+      int k = 0;
+      while (pad_unit[k] != u) ++k;
+      cntok[u] = nown[u] = pad_len[k];
+      src_base[u] = -1 - (int64_t)padlog_off[k];
+      ucls[u] = k;
+    }
+    nblk[u] = (cntok[u] + 31) / 32;
     DC_REQUIRE(slots < ((int64_t)1 << 31) - 64, "batch too large for 32-bit token offsets");
-    toff[r] = (int32_t)slots;
-    slots += ((int64_t)h_ntok[r] + 3) & ~(int64_t)3;
-    maxP = std::max(maxP, nblk[r]);
-    minP = std::min(minP, nblk[r]);
+    toff[u] = (int32_t)slots;
+    ctoff[u] = toff[u] - upv[u];
+    slots += ((int64_t)nown[u] + 3) & ~(int64_t)3;
+    maxP = std::max(maxP, nblk[u]);
+    minP = std::min(minP, nblk[u]);
   }
+  for (int r = 0; r < n_reads; ++r)
+    if (pv[r] > 0) padoff[r] = toff[pad_unit[ucls[r]]];
   const int64_t Tp = ((slots + 32 + 255) / 256) * 256;  // + slack, then a multiple of every GEMM token tile
   DC_REQUIRE(Tp < ((int64_t)1 << 31), "batch too large (token count must fit int32)");
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
-  const int64_t n_tb = Tp / 4;  // entries of the slot -> read map (one per 4 slots)
+  const int64_t n_tb = Tp / 4;  // entries of the slot -> unit map (one per 4 slots)
 
-  // Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by transform size: up to 2^14
-  // tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form; the others form groups
-  // of 32 reads of similar length (longest first) for the block-Toeplitz kernel.
-  std::vector<int32_t> order(n_reads);
+  // FFT classes by transform size; the others form groups of 32 units of similar length (longest first) for the
+  // block-Toeplitz kernel.
+  std::vector<int32_t> order(n_units);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
   std::vector<int32_t> fft_lists[6], mfma_order;
-  for (int j = 0; j < n_reads; ++j) {
-    const int r = order[j], nt = h_ntok[r];
-    if (nt > m->fft_min_tokens && nt <= (1 << 15) + 1) {
-      int logm = 10;
-      while ((1 << logm) < nt && logm < 15) ++logm;  // 2^15 + 1 tokens still fit the 2^15 form (one tap added by hand)
-      fft_lists[logm - 10].push_back(r);
-    } else {
-      mfma_order.push_back(r);
-    }
+  for (int j = 0; j < n_units; ++j) {
+    const int u = order[j];
+    if (ucls[u] > 0) fft_lists[ucls[u] - 1].push_back(u);
+    else mfma_order.push_back(u);
   }
   const int n_mfma = (int)mfma_order.size();
   const int n_groups = (n_mfma + 31) / 32;
@@ -512,25 +580,44 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
   }
-  std::vector<int32_t> blk_read(n_tb, -1);  // read that owns slots [4 i, 4 i + 4), -1 = none
-  std::vector<int64_t> src_base(n_reads);
-  for (int r = 0; r < n_reads; ++r) {
-    const int64_t q0 = toff[r] / 4, q1 = q0 + (h_ntok[r] + 3) / 4;
-    std::fill(blk_read.begin() + q0, blk_read.begin() + q1, r);
-    src_base[r] = (int64_t)r * row_stride + h_first[r];
+  std::vector<int32_t> blk_read(n_tb, -1);  // unit that owns slots [4 i, 4 i + 4), -1 = none
+  for (int u = 0; u < n_units; ++u) {
+    const int64_t q0 = toff[u] / 4, q1 = q0 + (nown[u] + 3) / 4;
+    std::fill(blk_read.begin() + q0, blk_read.begin() + q1, u);
+  }
+  // pad columns of the caller's dense logits <- the shared rows' logits
+  std::vector<int64_t> fill_dst(std::max(n_fill, 1));
+  std::vector<int32_t> fill_n(std::max(n_fill, 1)), fill_src(std::max(n_fill, 1));
+  if (h_npad) {
+    int j = 0;
+    for (int r = 0; r < n_reads; ++r)
+      if (pv[r] > 0) {  // (the last <= 3 pads of a run are the read's own: their logits come from its own slots)
+        fill_dst[j] = (int64_t)r * row_stride + h_first[r];
+        fill_n[j] = pv[r];
+        fill_src[j] = padlog_off[ucls[r]];
+        ++j;
+      }
   }
 
   // layout inside one staging / device buffer (all 8-byte aligned)
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+  const size_t nu = (size_t)n_units, i4 = sizeof(int32_t);
   size_t o_src = 0;
-  size_t o_blk = al8(o_src + sizeof(int64_t) * n_reads);
-  size_t o_toff = al8(o_blk + sizeof(int32_t) * n_tb);
-  size_t o_ntok = al8(o_toff + sizeof(int32_t) * n_reads);
-  size_t o_nblk = al8(o_ntok + sizeof(int32_t) * n_reads);
-  size_t o_gr = al8(o_nblk + sizeof(int32_t) * n_reads);
-  size_t o_gp = al8(o_gr + sizeof(int32_t) * grp_reads.size());
-  size_t o_fr = al8(o_gp + sizeof(int32_t) * grp_P.size());
-  size_t total = al8(o_fr + sizeof(int32_t) * std::max<size_t>(fft_reads.size(), 1));
+  size_t o_fdst = al8(o_src + sizeof(int64_t) * nu);
+  size_t o_blk = al8(o_fdst + sizeof(int64_t) * fill_dst.size());
+  size_t o_toff = al8(o_blk + i4 * n_tb);
+  size_t o_ntok = al8(o_toff + i4 * nu);
+  size_t o_nblk = al8(o_ntok + i4 * nu);
+  size_t o_ctoff = al8(o_nblk + i4 * nu);
+  size_t o_cntok = al8(o_ctoff + i4 * nu);
+  size_t o_pv = al8(o_cntok + i4 * nu);
+  size_t o_pad = al8(o_pv + i4 * nu);
+  size_t o_fn = al8(o_pad + i4 * nu);
+  size_t o_fs = al8(o_fn + i4 * fill_n.size());
+  size_t o_gr = al8(o_fs + i4 * fill_src.size());
+  size_t o_gp = al8(o_gr + i4 * grp_reads.size());
+  size_t o_fr = al8(o_gp + i4 * grp_P.size());
+  size_t total = al8(o_fr + i4 * std::max<size_t>(fft_reads.size(), 1));
 
   if (m->staging_pending) {
     DC_HIP_CHECK(hipEventSynchronize(m->staging_done));
@@ -547,30 +634,52 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     int rc = ensure(m->idx, total);
     if (rc) return rc;
   }
+  if (sp && m->padlog.bytes < (size_t)padlog_len * 2 * sizeof(float)) {
+    DC_HIP_CHECK(hipStreamSynchronize(st));
+    int rc = ensure(m->padlog, (size_t)padlog_len * 2 * sizeof(float));
+    if (rc) return rc;
+  }
   char* hp = (char*)m->pinned;
-  memcpy(hp + o_src, src_base.data(), sizeof(int64_t) * n_reads);
-  memcpy(hp + o_blk, blk_read.data(), sizeof(int32_t) * n_tb);
-  memcpy(hp + o_toff, toff.data(), sizeof(int32_t) * n_reads);
-  memcpy(hp + o_ntok, h_ntok, sizeof(int32_t) * n_reads);
-  memcpy(hp + o_nblk, nblk.data(), sizeof(int32_t) * n_reads);
-  memcpy(hp + o_gr, grp_reads.data(), sizeof(int32_t) * grp_reads.size());
-  memcpy(hp + o_gp, grp_P.data(), sizeof(int32_t) * grp_P.size());
-  if (!fft_reads.empty()) memcpy(hp + o_fr, fft_reads.data(), sizeof(int32_t) * fft_reads.size());
+  memcpy(hp + o_src, src_base.data(), sizeof(int64_t) * nu);
+  memcpy(hp + o_fdst, fill_dst.data(), sizeof(int64_t) * fill_dst.size());
+  memcpy(hp + o_blk, blk_read.data(), i4 * n_tb);
+  memcpy(hp + o_toff, toff.data(), i4 * nu);
+  memcpy(hp + o_ntok, nown.data(), i4 * nu);
+  memcpy(hp + o_nblk, nblk.data(), i4 * nu);
+  memcpy(hp + o_ctoff, ctoff.data(), i4 * nu);
+  memcpy(hp + o_cntok, cntok.data(), i4 * nu);
+  memcpy(hp + o_pv, upv.data(), i4 * nu);
+  memcpy(hp + o_pad, padoff.data(), i4 * nu);
+  memcpy(hp + o_fn, fill_n.data(), i4 * fill_n.size());
+  memcpy(hp + o_fs, fill_src.data(), i4 * fill_src.size());
+  memcpy(hp + o_gr, grp_reads.data(), i4 * grp_reads.size());
+  memcpy(hp + o_gp, grp_P.data(), i4 * grp_P.size());
+  if (!fft_reads.empty()) memcpy(hp + o_fr, fft_reads.data(), i4 * fft_reads.size());
   DC_HIP_CHECK(hipMemcpyAsync(m->idx.p, m->pinned, total, hipMemcpyHostToDevice, st));
   DC_HIP_CHECK(hipEventRecord(m->staging_done, st));
   m->staging_pending = true;
 
   char* dp = (char*)m->idx.p;
   m->d_src_base = (int64_t*)(dp + o_src);
+  m->d_fill_dst = (int64_t*)(dp + o_fdst);
   m->d_blk_read = (int32_t*)(dp + o_blk);
   m->d_toff = (int32_t*)(dp + o_toff);
   m->d_ntok = (int32_t*)(dp + o_ntok);
   m->d_nblk = (int32_t*)(dp + o_nblk);
+  m->d_ctoff = (int32_t*)(dp + o_ctoff);
+  m->d_cntok = (int32_t*)(dp + o_cntok);
+  m->d_pv = (int32_t*)(dp + o_pv);
+  m->d_padoff = (int32_t*)(dp + o_pad);
+  m->d_fill_n = (int32_t*)(dp + o_fn);
+  m->d_fill_src = (int32_t*)(dp + o_fs);
   m->d_grp_reads = (int32_t*)(dp + o_gr);
   m->d_grp_P = (int32_t*)(dp + o_gp);
   m->d_fft_reads = (int32_t*)(dp + o_fr);
+  m->shared_prefix = sp;
+  m->n_fill_rows = n_fill;
+  m->pad_id = pad_id;
   m->max_P_mfma = maxP_mfma;
-  // reads are ordered longest first: the groups of more than 32 blocks (1 024 tokens) are a prefix
+  // units are ordered longest first: the groups of more than 32 blocks (1 024 tokens) are a prefix
   m->n_groups_long = 0;
   for (int g = 0; g < n_groups; ++g) m->n_groups_long += grp_P[g] > 32;
   m->Tp = Tp;
@@ -611,7 +720,7 @@ int run_head(dc_model* m, hipStream_t st, bool head_sums, bool head1_ready, floa
       return rc;
     ProfScope ps(m, st, "head_out");
     if ((rc = launch_head_reduce(st, (const float*)m->part.p, H / gemm6_channel_block(), m->b3, Tp, m->d_blk_read, m->d_toff,
-                                 m->d_src_base, m->d_ntok, d_logits)))
+                                 m->d_src_base, m->d_ntok, d_logits, (float*)m->padlog.p)))
       return rc;
   } else {
     if ((rc = run_gemm(m, st, "gemm_head2", WRef{m->Wt_l2, m->Wp_l2, m->Wq_l2, m->is_l2}, hm, ob, m->b_l2, hm, nullptr, false, EPI_BIAS_RES_RELU,
@@ -619,17 +728,18 @@ int run_head(dc_model* m, hipStream_t st, bool head_sums, bool head1_ready, floa
       return rc;
     ProfScope ps(m, st, "head_out");
     if ((rc = launch_head_out(st, ob, m->W3, m->b3, H, c.num_class, Tp, m->d_blk_read, m->d_toff, m->d_src_base,
-                              m->d_ntok, d_logits)))
+                              m->d_ntok, d_logits, (float*)m->padlog.p)))
       return rc;
   }
   return DC_OK;
 }
 
 int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, const float* d_quals, int n_reads,
-                 int64_t row_stride, const int32_t* h_first, const int32_t* h_ntok, float* d_logits) {
+                 int64_t row_stride, const int32_t* h_first, const int32_t* h_ntok, float* d_logits,
+                 const int32_t* h_npad = nullptr, int pad_id = 0) {
   const auto& c = m->cfg;
   int rc;
-  if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok))) return rc;
+  if ((rc = setup_geometry(m, st, n_reads, row_stride, h_first, h_ntok, h_npad, pad_id))) return rc;
   if ((rc = ensure_workspace(m, m->Tp))) return rc;
   // taps: the longest read, and every tap an FFT size class in use transforms (its spectrum is built from min(taps, M)
   // taps: materialising all M makes it -- and with it the last bits of the result -- independent of what the handle saw before)
@@ -678,9 +788,9 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
     ProfScope ps(m, st, "embed");
     rc = l0_table ? launch_embed_l0(st, d_ids, ids_i64, d_quals, m->emb, m->u_table0, c.vocab, D, m->d_blk_read,
                                     m->d_toff, m->d_src_base, m->d_ntok, Tp, x, l0_gather ? nullptr : u, qpad,
-                                    l0_gather ? tokp : nullptr)
+                                    l0_gather ? tokp : nullptr, m->pad_id)
                   : launch_embed(st, d_ids, ids_i64, d_quals, m->emb, c.vocab, D, m->d_blk_read, m->d_toff,
-                                 m->d_src_base, m->d_ntok, Tp, x, qpad);
+                                 m->d_src_base, m->d_ntok, Tp, x, qpad, m->pad_id);
     if (rc) return rc;
   }
   const bool no_mlp_chain = getenv("DC_NO_MLP_CHAIN") != nullptr;  // A/B switch
@@ -713,9 +823,13 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       a.sb = L.sb;
       a.grp_reads = m->d_grp_reads;
       a.grp_P = m->d_grp_P;
-      a.toff = m->d_toff;
+      a.toff = m->d_ctoff;   // the long convolution's view of a unit: its whole sequence, shared [PAD] prefix included
       a.nblk = m->d_nblk;
-      a.ntok = m->d_ntok;
+      a.ntok = m->d_cntok;
+      if (m->shared_prefix) {
+        a.pv = m->d_pv;
+        a.padoff = m->d_padoff;
+      }
       a.Tp = Tp;
       a.D = D;
       a.kfp = L.kfp;
@@ -836,7 +950,13 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         return rc;
     }
   }
-  return run_head(m, st, fused_stats && l0_table, head1_ready, d_logits);
+  if ((rc = run_head(m, st, fused_stats && l0_table, head1_ready, d_logits))) return rc;
+  if (m->n_fill_rows > 0) {  // shared [PAD] rows: their logits into every row's pad columns (+ the contract check)
+    ProfScope ps(m, st, "pad_fill");
+    return launch_fill_pad_logits(st, d_ids, ids_i64, d_quals, m->n_fill_rows, m->max_P * 32, m->d_fill_dst, m->d_fill_n,
+                                  m->d_fill_src, (const float*)m->padlog.p, m->pad_id, d_logits, m->d_prefix_bad);
+  }
+  return DC_OK;
 }
 
 }  // namespace
@@ -870,6 +990,10 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     if (rc0) return rc0;
     m->d_overflow = (int*)p;
     DC_HIP_CHECK(hipMemset(p, 0, sizeof(int)));
+    void* pb = nullptr;
+    if ((rc0 = dev_alloc(m, sizeof(int), &pb))) return rc0;
+    m->d_prefix_bad = (int*)pb;
+    DC_HIP_CHECK(hipMemset(pb, 0, sizeof(int)));
     DC_HIP_CHECK(hipStreamSynchronize(nullptr));  // NULL-stream memset: complete before any caller stream can touch it
   }
   const int D = cfg->d_model, DI = cfg->d_inner, H = cfg->head_hidden, fo = cfg->filter_order, emb = cfg->emb_dim;
@@ -993,7 +1117,8 @@ extern "C" void dc_model_free(dc_model* m) {
       if (p) (void)hipFree(p);
   }
   if (m->fft_tw) (void)hipFree(m->fft_tw);
-  for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part})
+  for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part, &m->tok, &m->padlog,
+                    &m->fft_scratch})
     if (b->p) (void)hipFree(b->p);
   if (m->pinned) (void)hipHostFree(m->pinned);
   if (m->staging_done) (void)hipEventDestroy(m->staging_done);
@@ -1021,6 +1146,28 @@ extern "C" int dc_forward_ragged(dc_model* m, void* stream, const void* d_input_
   DC_REQUIRE(n_reads >= 1 && row_stride >= 1, "n_reads and row_stride must be positive");
   return forward_core(m, as_stream(stream), d_input_ids, ids_i64, d_input_quals, n_reads, row_stride, h_first,
                       h_n_tokens, d_logits);
+}
+
+extern "C" int dc_forward_shared_prefix(dc_model* m, void* stream, const void* d_input_ids, int32_t ids_i64,
+                                        const float* d_input_quals, int32_t n_reads, int64_t row_stride,
+                                        const int32_t* h_first, const int32_t* h_n_tokens, const int32_t* h_n_pad,
+                                        int32_t pad_token_id, float* d_logits) {
+  DC_REQUIRE(m && d_input_ids && d_input_quals && d_logits && h_first && h_n_tokens && h_n_pad, "null pointer");
+  DC_REQUIRE(n_reads >= 1 && row_stride >= 1, "n_reads and row_stride must be positive");
+  DC_REQUIRE(pad_token_id >= 0 && pad_token_id < m->cfg.vocab, "pad_token_id outside the vocabulary");
+  return forward_core(m, as_stream(stream), d_input_ids, ids_i64, d_input_quals, n_reads, row_stride, h_first,
+                      h_n_tokens, d_logits, h_n_pad, pad_token_id);
+}
+
+extern "C" int dc_model_prefix_violations(dc_model* m, void* stream, int32_t* count) {
+  DC_REQUIRE(m && count, "null pointer");
+  hipStream_t st = as_stream(stream);
+  int v = 0;
+  DC_HIP_CHECK(hipMemcpyAsync(&v, m->d_prefix_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+  DC_HIP_CHECK(hipStreamSynchronize(st));
+  if (v) DC_HIP_CHECK(hipMemsetAsync(m->d_prefix_bad, 0, sizeof(int), st));
+  *count = v;
+  return DC_OK;
 }
 
 extern "C" int dc_head_forward(dc_model* m, void* stream, const float* d_hidden, const float* d_input_quals,

@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
                                                     const int32_t* __restrict__ toff,
                                                     const int64_t* __restrict__ src_base,
                                                     const int32_t* __restrict__ ntok, int64_t Tp,
-                                                    float* __restrict__ x, float* __restrict__ qpad) {
+                                                    float* __restrict__ x, float* __restrict__ qpad, int pad_id) {
   extern __shared__ float s_emb[];  // [vocab][D]
   for (int j = threadIdx.x; j < vocab * D; j += 256) s_emb[j] = emb[j];
   __syncthreads();
@@ -1377,8 +1377,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const IdT* __restrict__ ids,
     const int l = (int)(t - toff[r]);
     if (l < ntok[r]) {
       const int64_t s = src_base[r] + l;
-      id = (int)ids[s];
-      qv = quals[s];
+      if (src_base[r] < 0) {  // a shared [PAD] row (dc_forward_shared_prefix): constant tokens, quality 0
+        id = pad_id;
+      } else {
+        id = (int)ids[s];
+        qv = quals[s];
+      }
       if (id < 0 || id >= vocab) id = -1;  // out-of-vocabulary ids cannot occur from dc_tokenize_batch
     }
   }
@@ -1543,6 +1547,7 @@ constexpr int HY_ZSTRIDE = 36;  // floats per read row of the z tile: 16-B align
 #endif
 constexpr int HY_NW = DC_HY_NW, HY_ACC = 32 / HY_NW;
 
+template <bool SP>  // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
 __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_kernel(HyenaArgs a) {
   extern __shared__ float s_mem[];
   const int g = blockIdx.x;
@@ -1573,8 +1578,11 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   if (!z_valid) rz = a.grp_reads[g * 32];
   const int64_t z_off = a.toff[rz];
   const int z_nblk = z_valid ? a.nblk[rz] : 0;
-  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + z_off;
-  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + z_off;
+  const int z_pv = SP ? a.pv[rz] : 0;             // positions in front of it come from the shared [PAD] row
+  const int64_t z_pad = SP ? a.padoff[rz] : 0;
+  auto zslot = [&](int64_t t) -> int64_t { return (SP && t < z_pv ? z_pad : z_off) + t; };  // slot of the quad at position t
+  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp;
+  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp;
   const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
               bx1 = a.sb[a.D + c];
   const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
@@ -1585,11 +1593,13 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
     if (producer && p < z_nblk) {
       const int64_t t = 32 * p + zq4;
       if (t > 0) {
-        l1 = *reinterpret_cast<const float4*>(ux1 + t - 4);
-        lv = *reinterpret_cast<const float4*>(uv + t - 4);
+        const int64_t sl = zslot(t - 4);
+        l1 = *reinterpret_cast<const float4*>(ux1 + sl);
+        lv = *reinterpret_cast<const float4*>(uv + sl);
       }
-      c1 = *reinterpret_cast<const float4*>(ux1 + t);
-      cv = *reinterpret_cast<const float4*>(uv + t);
+      const int64_t sc = zslot(t);
+      c1 = *reinterpret_cast<const float4*>(ux1 + sc);
+      cv = *reinterpret_cast<const float4*>(uv + sc);
     }
   };
   auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
@@ -1657,7 +1667,10 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   const int64_t off = a.toff[r];
   const int my_nblk = valid ? a.nblk[r] : 0;
   const int my_nt4 = valid ? (a.ntok[r] + 3) & ~3 : 0;  // slots the read owns (stores beyond belong to the next read)
-  const float* ux0 = a.u + (int64_t)c * a.Tp + off;
+  const int my_pv = SP ? a.pv[r] : 0;                    // ... and those in front of position pv are the shared [PAD] row's
+  const int64_t my_pad = SP ? a.padoff[r] : 0;
+  auto xslot = [&](int64_t t) -> int64_t { return (SP && t < my_pv ? my_pad : off) + t; };
+  const float* ux0 = a.u + (int64_t)c * a.Tp;
   float* yrow = a.y + (int64_t)c * a.Tp + off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
 #pragma unroll
@@ -1668,8 +1681,8 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
       for (int gq = 0; gq < 4; ++gq) {
         const int64_t t = 32 * pp + 8 * gq + 4 * h;
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t > 0) lo = *reinterpret_cast<const float4*>(ux0 + t - 4);
-        const float4 cu = *reinterpret_cast<const float4*>(ux0 + t);
+        if (t > 0) lo = *reinterpret_cast<const float4*>(ux0 + xslot(t - 4));
+        const float4 cu = *reinterpret_cast<const float4*>(ux0 + xslot(t));
         const float g0 = fmaf(wx0_0, lo.z, fmaf(wx0_1, lo.w, fmaf(wx0_2, cu.x, bx0)));
         const float g1 = fmaf(wx0_0, lo.w, fmaf(wx0_1, cu.x, fmaf(wx0_2, cu.y, bx0)));
         const float g2 = fmaf(wx0_0, cu.x, fmaf(wx0_1, cu.y, fmaf(wx0_2, cu.z, bx0)));
@@ -1679,7 +1692,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
         o.y = acc[m][4 * gq + 1] * g1;
         o.z = acc[m][4 * gq + 2] * g2;
         o.w = acc[m][4 * gq + 3] * g3;
-        if (t < my_nt4) *reinterpret_cast<float4*>(yrow + t) = o;
+        if (t < my_nt4 && t >= my_pv) *reinterpret_cast<float4*>(yrow + t) = o;
       }
     }
   }
@@ -1690,8 +1703,12 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   // LDS of the largest chunk: filter taps [32 + 32 * 32 * n_oc] + two z tiles
   const size_t lds = ((size_t)32 + 32 * 32 * (size_t)n_oc + 2 * 32 * HY_ZSTRIDE) * sizeof(float);
   DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel, 160 * 1024);  // the permitted maximum; a launch asks for `lds`
-  hipLaunchKernelGGL(hyena2_kernel, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<false>, 160 * 1024);  // the permitted maximum; a launch asks for `lds`
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<true>, 160 * 1024);
+  if (a.pv)
+    hipLaunchKernelGGL(hyena2_kernel<true>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
+  else
+    hipLaunchKernelGGL(hyena2_kernel<false>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
@@ -1801,8 +1818,9 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
   return DC_OK;
 }
 
-template <int CB, int MODE, bool TAB>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16;
-                                       // TAB: u gathered from the layer-0 table by token id (HyenaArgs::tok / tab)
+template <int CB, int MODE, bool TAB, bool SP>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16;
+                                                // TAB: u gathered from the layer-0 table by token id (HyenaArgs::tok / tab);
+                                                // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
 #ifndef DC_H3_OCC
 #define DC_H3_OCC 2
 #endif
@@ -1836,15 +1854,18 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   int rz = a.grp_reads[g * 32 + zr];
   const bool z_valid = rz >= 0;
   if (!z_valid) rz = a.grp_reads[g * 32];
-  const int64_t z_off = a.toff[rz];
+  const int z_off = a.toff[rz];
   const int z_nblk = z_valid ? a.nblk[rz] : 0;
-  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp + z_off;
-  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + z_off;
+  const int z_pv = SP ? a.pv[rz] : 0;          // positions in front of it come from the shared [PAD] row
+  const int z_pad = SP ? a.padoff[rz] : 0;
+  auto zslot = [&](int t) -> int { return (SP && t < z_pv ? z_pad : z_off) + t; };  // slot of the quad at position t
+  const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp;
+  const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp;
   const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
               bx1 = a.sb[a.D + c];
   const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
               wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
-  const unsigned char* tkz = TAB ? a.tok + z_off : nullptr;
+  const unsigned char* tkz = TAB ? a.tok : nullptr;
   if (TAB) {
     if (tid < 3 * 17) {
       const int k3 = tid / 17, id = tid - 17 * k3;
@@ -1861,22 +1882,24 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     if (TAB) {  // the token ids of positions t-4 .. t+3 travel in l1.x / c1.x; z_store looks the values up
       uint32_t il = 0xFFFFFFFFu, ic = 0xFFFFFFFFu;
       if (p < z_nblk) {
-        const int64_t t = 32 * p + zq4;
-        if (t > 0) il = *reinterpret_cast<const uint32_t*>(tkz + t - 4);
-        ic = *reinterpret_cast<const uint32_t*>(tkz + t);
+        const int t = 32 * p + zq4;
+        if (t > 0) il = *reinterpret_cast<const uint32_t*>(tkz + zslot(t - 4));
+        ic = *reinterpret_cast<const uint32_t*>(tkz + zslot(t));
       }
       l1.x = __builtin_bit_cast(float, il);
       c1.x = __builtin_bit_cast(float, ic);
       return;
     }
     if (p < z_nblk) {
-      const int64_t t = 32 * p + zq4;
+      const int t = 32 * p + zq4;
       if (t > 0) {
-        l1 = *reinterpret_cast<const float4*>(ux1 + t - 4);
-        lv = *reinterpret_cast<const float4*>(uv + t - 4);
+        const int sl = zslot(t - 4);
+        l1 = *reinterpret_cast<const float4*>(ux1 + sl);
+        lv = *reinterpret_cast<const float4*>(uv + sl);
       }
-      c1 = *reinterpret_cast<const float4*>(ux1 + t);
-      cv = *reinterpret_cast<const float4*>(uv + t);
+      const int sc = zslot(t);
+      c1 = *reinterpret_cast<const float4*>(ux1 + sc);
+      cv = *reinterpret_cast<const float4*>(uv + sc);
     }
   };
   // Inside the tile loop only the current four tokens are loaded: the two tokens in front of them are the last two of
@@ -1888,14 +1911,14 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     c1 = cv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (TAB) {
       uint32_t ic = 0xFFFFFFFFu;
-      if (p < z_nblk) ic = *reinterpret_cast<const uint32_t*>(tkz + 32 * p + zq4);
+      if (p < z_nblk) ic = *reinterpret_cast<const uint32_t*>(tkz + zslot(32 * p + zq4));
       c1.x = __builtin_bit_cast(float, ic);
       return;
     }
     if (p < z_nblk) {
-      const int64_t t = 32 * p + zq4;
-      c1 = *reinterpret_cast<const float4*>(ux1 + t);
-      cv = *reinterpret_cast<const float4*>(uv + t);
+      const int sc = zslot(32 * p + zq4);
+      c1 = *reinterpret_cast<const float4*>(ux1 + sc);
+      cv = *reinterpret_cast<const float4*>(uv + sc);
     }
   };
   auto from_below = [&](float own, float carried) -> float {  // row_shr:1 / row_shl:7 of a DPP row of 16 lanes
@@ -2076,12 +2099,15 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   if (MODE == 1 && __any(ovf) && lane == 0) atomicAdd(a.overflow, 1);
   const int sq = (lane & 7) * 4, srs = lane >> 3;
   int s_off[4], s_nblk[4], s_nt4[4];  // per i: the read's slot offset / blocks / owned slots (0: no such read)
+  int s_pv[4], s_pad[4];              // SP: positions in front of s_pv[i] live in the shared [PAD] row, at slot s_pad[i] + t
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rr = a.grp_reads[g * 32 + 8 * i + srs];
     s_off[i] = rr >= 0 ? (int)a.toff[rr] : 0;
     s_nblk[i] = rr >= 0 ? a.nblk[rr] : 0;
     s_nt4[i] = rr >= 0 ? (a.ntok[rr] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
+    s_pv[i] = SP && rr >= 0 ? a.pv[rr] : 0;
+    s_pad[i] = SP && rr >= 0 ? a.padoff[rr] : 0;
   }
   float* const ychan = a.y + (int64_t)c * a.Tp;
   const float* const x0chan = a.u + (int64_t)c * a.Tp;
@@ -2098,13 +2124,13 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     for (int i = 0; i < 4; ++i) {
       const int ppc = pp < s_nblk[i] ? pp : (s_nblk[i] > 0 ? s_nblk[i] - 1 : 0);
       const int t = 32 * ppc + sq, tp = t >= 2 ? t - 2 : 0;
+      const int st = (SP && t < s_pv[i] ? s_pad[i] : s_off[i]) + t, stp = (SP && tp < s_pv[i] ? s_pad[i] : s_off[i]) + tp;
       if (TAB) {
-        const unsigned char* tk = a.tok + s_off[i];
-        xw[i].cur = make_float4(__builtin_bit_cast(float, *reinterpret_cast<const uint32_t*>(tk + t)), 0.f, 0.f, 0.f);
-        xw[i].prv = make_float2(__builtin_bit_cast(float, (uint32_t)*reinterpret_cast<const unsigned short*>(tk + tp)), 0.f);
+        xw[i].cur = make_float4(__builtin_bit_cast(float, *reinterpret_cast<const uint32_t*>(a.tok + st)), 0.f, 0.f, 0.f);
+        xw[i].prv = make_float2(__builtin_bit_cast(float, (uint32_t)*reinterpret_cast<const unsigned short*>(a.tok + stp)), 0.f);
       } else {
-        xw[i].cur = *reinterpret_cast<const float4*>(x0chan + s_off[i] + t);
-        xw[i].prv = *reinterpret_cast<const float2*>(x0chan + s_off[i] + tp);
+        xw[i].cur = *reinterpret_cast<const float4*>(x0chan + st);
+        xw[i].prv = *reinterpret_cast<const float2*>(x0chan + stp);
       }
     }
   };
@@ -2123,7 +2149,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
       const int ts = 32 * pp + sq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (pp < s_nblk[i] && ts < s_nt4[i]) {
+        if (pp < s_nblk[i] && ts < s_nt4[i] && ts >= s_pv[i]) {
           const XWin& xw = xq[m & 1][i];
           float w[6];
           if (TAB) {
@@ -2159,16 +2185,16 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 #endif
 }
 
-template <int MODE, bool TAB>
+template <int MODE, bool TAB, bool SP>
 static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<32, MODE, TAB>), lds);
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<16, MODE, TAB>), lds);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<32, MODE, TAB, SP>), lds);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<16, MODE, TAB, SP>), lds);
   const bool cb16 = getenv("DC_H3_CB16") != nullptr;  // A/B: 16-block output chunks also for short reads
   if (max_P <= 32 && !cb16) {
-    hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<32, MODE, TAB, SP>), dim3(n_groups, a.D, 1), dim3(256), lds, st, a);
   } else {
-    hipLaunchKernelGGL((hyena3_kernel<16, MODE, TAB>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((hyena3_kernel<16, MODE, TAB, SP>), dim3(n_groups, a.D, (max_P + 15) / 16), dim3(256), lds, st, a);
   }
   DC_LAUNCH_CHECK();
   return DC_OK;
@@ -2184,15 +2210,20 @@ int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   // fp16 planes, 64 with the bf16 ones; DC_H3_WS=0 keeps hyena3_kernel (A/B, parity)
   const char* ws_env = getenv("DC_H3_WS");
   const bool ws_on = !(ws_env && atoi(ws_env) == 0) && !getenv("DC_H3_CB16");
+  const bool sp = a.pv != nullptr;
+  if (sp) DC_REQUIRE(a.padoff, "shared [PAD] prefix: pv without padoff");
+  // (mode, table gather, shared prefix) -> instantiation
+#define DC_H_DISPATCH(fn, MODE)                                                                                   \
+  return sp ? (tab ? fn<MODE, true, true>(st, a, n_groups, max_P) : fn<MODE, false, true>(st, a, n_groups, max_P)) \
+            : (tab ? fn<MODE, true, false>(st, a, n_groups, max_P) : fn<MODE, false, false>(st, a, n_groups, max_P))
   if (a.split_mode == 1) {
     DC_REQUIRE(a.kfp_f16 && a.ch_inv_scale && a.overflow, "fp16x3 long convolution needs its planes / scales / guard");
-    if (ws_on && max_P <= 32 * h4_max_chunks(2))
-      return tab ? launch_hyena4_t<1, true>(st, a, n_groups, max_P) : launch_hyena4_t<1, false>(st, a, n_groups, max_P);
-    return tab ? launch_hyena3_t<1, true>(st, a, n_groups, max_P) : launch_hyena3_t<1, false>(st, a, n_groups, max_P);
+    if (ws_on && max_P <= 32 * h4_max_chunks(2)) DC_H_DISPATCH(launch_hyena4_t, 1);
+    DC_H_DISPATCH(launch_hyena3_t, 1);
   }
-  if (ws_on && max_P <= 32 * h4_max_chunks(3))
-    return tab ? launch_hyena4_t<0, true>(st, a, n_groups, max_P) : launch_hyena4_t<0, false>(st, a, n_groups, max_P);
-  return tab ? launch_hyena3_t<0, true>(st, a, n_groups, max_P) : launch_hyena3_t<0, false>(st, a, n_groups, max_P);
+  if (ws_on && max_P <= 32 * h4_max_chunks(3)) DC_H_DISPATCH(launch_hyena4_t, 0);
+  DC_H_DISPATCH(launch_hyena3_t, 0);
+#undef DC_H_DISPATCH
 }
 
 // =====================================================================================
@@ -2204,7 +2235,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ toff,
                                                        const int64_t* __restrict__ src_base,
                                                        const int32_t* __restrict__ ntok,
-                                                       float* __restrict__ logits) {
+                                                       float* __restrict__ logits, float* __restrict__ padlog) {
   extern __shared__ float s_w3[];  // [C][H]
   for (int j = threadIdx.x; j < C * H; j += 256) s_w3[j] = w3[j];
   __syncthreads();
@@ -2223,7 +2254,8 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
   float2 out;
   out.x = acc0 + b3[0];
   out.y = acc1 + b3[1];
-  *reinterpret_cast<float2*>(logits + (src_base[r] + l) * 2) = out;
+  const int64_t sb = src_base[r];  // < 0: a shared [PAD] row, its logits go to the side buffer (dc_forward_shared_prefix)
+  *reinterpret_cast<float2*>(sb >= 0 ? logits + (sb + l) * 2 : padlog + (-1 - sb + l) * 2) = out;
 }
 
 // logits[t] = b3 + sum over the n_part channel blocks of the fused linear3 partials (fixed order)
@@ -2233,7 +2265,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
                                                           const int32_t* __restrict__ toff,
                                                           const int64_t* __restrict__ src_base,
                                                           const int32_t* __restrict__ ntok,
-                                                          float* __restrict__ logits) {
+                                                          float* __restrict__ logits, float* __restrict__ padlog) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= Tp) return;
   const int r = blk_read[t >> 2];
@@ -2246,14 +2278,15 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     acc.x += v.x;
     acc.y += v.y;
   }
-  *reinterpret_cast<float2*>(logits + (src_base[r] + l) * 2) = acc;
+  const int64_t sb = src_base[r];  // < 0: a shared [PAD] row, its logits go to the side buffer (dc_forward_shared_prefix)
+  *reinterpret_cast<float2*>(sb >= 0 ? logits + (sb + l) * 2 : padlog + (-1 - sb + l) * 2) = acc;
 }
 
 int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
                        const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                       float* logits) {
+                       float* logits, float* padlog) {
   hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((Tp + 255) / 256)), dim3(256), 0, st, part, n_part, b3, Tp,
-                     blk_read, toff, src_base, ntok, logits);
+                     blk_read, toff, src_base, ntok, logits, padlog);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
@@ -2269,7 +2302,8 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
                                                        const int64_t* __restrict__ src_base,
                                                        const int32_t* __restrict__ ntok, int64_t Tp,
                                                        float* __restrict__ x, float* __restrict__ u,
-                                                       float* __restrict__ qpad, unsigned char* __restrict__ tok) {
+                                                       float* __restrict__ qpad, unsigned char* __restrict__ tok,
+                                                       int pad_id) {
   extern __shared__ float s_tab[];  // [vocab][D] then [vocab][3D]
   float* s_emb = s_tab;
   float* s_u = s_tab + vocab * D;
@@ -2286,8 +2320,12 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
     const int l = (int)(t - toff[r]);
     if (l < ntok[r]) {
       const int64_t sidx = src_base[r] + l;
-      id = (int)ids[sidx];
-      qv = quals[sidx];
+      if (src_base[r] < 0) {  // a shared [PAD] row (dc_forward_shared_prefix): constant tokens, quality 0
+        id = pad_id;
+      } else {
+        id = (int)ids[sidx];
+        qv = quals[sidx];
+      }
       if (id < 0 || id >= vocab) id = -1;
     }
   }
@@ -2301,31 +2339,67 @@ __global__ __launch_bounds__(256) void embed_l0_kernel(const IdT* __restrict__ i
 int launch_embed_l0(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb,
                     const float* u_table, int vocab, int D, const int32_t* blk_read, const int32_t* toff,
                     const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x, float* u, float* qpad,
-                    unsigned char* tok) {
+                    unsigned char* tok, int pad_id) {
   const unsigned grid = (unsigned)((Tp + 255) / 256);
   const size_t lds = (size_t)vocab * D * 4 * sizeof(float);
   DC_REQUIRE(lds <= 64 * 1024, "embedding tables do not fit the default LDS allocation");
   if (ids_i64)
     hipLaunchKernelGGL(embed_l0_kernel<int64_t>, dim3(grid), dim3(256), lds, st, (const int64_t*)ids, quals, emb,
-                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok);
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok, pad_id);
   else
     hipLaunchKernelGGL(embed_l0_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)ids, quals, emb,
-                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok);
+                       u_table, vocab, D, blk_read, toff, src_base, ntok, Tp, x, u, qpad, tok, pad_id);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
 
 int launch_embed(hipStream_t st, const void* ids, int ids_i64, const float* quals, const float* emb, int vocab, int D,
                  const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                 int64_t Tp, float* x, float* qpad) {
+                 int64_t Tp, float* x, float* qpad, int pad_id) {
   const unsigned grid = (unsigned)((Tp + 255) / 256);
   const size_t lds = (size_t)vocab * D * sizeof(float);
   if (ids_i64)
     hipLaunchKernelGGL(embed_kernel<int64_t>, dim3(grid), dim3(256), lds, st, (const int64_t*)ids, quals, emb, vocab,
-                       D, blk_read, toff, src_base, ntok, Tp, x, qpad);
+                       D, blk_read, toff, src_base, ntok, Tp, x, qpad, pad_id);
   else
     hipLaunchKernelGGL(embed_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)ids, quals, emb, vocab,
-                       D, blk_read, toff, src_base, ntok, Tp, x, qpad);
+                       D, blk_read, toff, src_base, ntok, Tp, x, qpad, pad_id);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+// dc_forward_shared_prefix: the pad columns of the caller's dense logits <- the logits of the shared [PAD] row, and the
+// contract check on the way: every position of a declared pad run must hold ([PAD], quality 0) -- the model never read them.
+template <typename IdT>
+__global__ __launch_bounds__(256) void fill_pad_logits_kernel(const IdT* __restrict__ ids, const float* __restrict__ quals,
+                                                              const int64_t* __restrict__ fill_dst,
+                                                              const int32_t* __restrict__ fill_n,
+                                                              const int32_t* __restrict__ fill_src,
+                                                              const float* __restrict__ padlog, int pad_id,
+                                                              float* __restrict__ logits, int* __restrict__ bad) {
+  const int j = blockIdx.x;
+  const int n = fill_n[j];
+  const int64_t dst = fill_dst[j];
+  const float2* src = reinterpret_cast<const float2*>(padlog) + fill_src[j];
+  bool wrong = false;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += 256 * gridDim.y) {
+    *reinterpret_cast<float2*>(logits + (dst + i) * 2) = src[i];
+    wrong = wrong || (int)ids[dst + i] != pad_id || quals[dst + i] != 0.f;
+  }
+  if (__any(wrong) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1);
+}
+
+int launch_fill_pad_logits(hipStream_t st, const void* ids, int ids_i64, const float* quals, int n_rows, int max_run,
+                           const int64_t* fill_dst, const int32_t* fill_n, const int32_t* fill_src, const float* padlog,
+                           int pad_id, float* logits, int* bad) {
+  if (n_rows <= 0) return DC_OK;
+  const dim3 grid((unsigned)n_rows, (unsigned)std::min(std::max((max_run + 2047) / 2048, 1), 16));
+  if (ids_i64)
+    hipLaunchKernelGGL(fill_pad_logits_kernel<int64_t>, grid, dim3(256), 0, st, (const int64_t*)ids, quals, fill_dst, fill_n,
+                       fill_src, padlog, pad_id, logits, bad);
+  else
+    hipLaunchKernelGGL(fill_pad_logits_kernel<uint8_t>, grid, dim3(256), 0, st, (const uint8_t*)ids, quals, fill_dst, fill_n,
+                       fill_src, padlog, pad_id, logits, bad);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
@@ -2339,10 +2413,10 @@ int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps
 
 int launch_head_out(hipStream_t st, const float* o, const float* w3, const float* b3, int H, int C, int64_t Tp,
                     const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
-                    float* logits) {
+                    float* logits, float* padlog) {
   DC_REQUIRE(C == 2, "head_out supports num_class == 2");
   hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)((Tp + 255) / 256)), dim3(256), (size_t)C * H * sizeof(float), st,
-                     o, w3, b3, H, C, Tp, blk_read, toff, src_base, ntok, logits);
+                     o, w3, b3, H, C, Tp, blk_read, toff, src_base, ntok, logits, padlog);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -242,7 +242,7 @@ __global__ __launch_bounds__((1 << LOGM) / 16) void hyena_fft_filter_kernel(cons
 // ---------------------------------------------------------------------------------------------------
 // the operator for one (read, channel)
 // ---------------------------------------------------------------------------------------------------
-template <int LOGM, bool TAB>
+template <int LOGM, bool TAB, bool SP>  // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
 __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
                                                                        const float2* __restrict__ tw,
                                                                        const float2* __restrict__ spec) {
@@ -251,13 +251,15 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
   float2* s = reinterpret_cast<float2*>(s_raw);
   float* s_tab = reinterpret_cast<float*>(s + (M + M / 16));  // TAB: x0 | x1 | v of this channel for ids 0..15, [16] = 0
   const int r = reads[blockIdx.x], c = blockIdx.y, tid = threadIdx.x;
-  const int64_t toff = a.toff[r];
+  const int toff = a.toff[r];
   const int L = a.ntok[r];
   const int D = a.D;
-  const float* ux0 = a.u + (int64_t)c * a.Tp + toff;
-  const float* ux1 = a.u + (int64_t)(D + c) * a.Tp + toff;
-  const float* uv = a.u + (int64_t)(2 * D + c) * a.Tp + toff;
-  const unsigned char* tok = TAB ? a.tok + toff : nullptr;
+  const int pv = SP ? a.pv[r] : 0, padoff = SP ? a.padoff[r] : 0;  // positions < pv live in the shared [PAD] row (pv: a multiple of 4)
+  auto slot = [&](int t) -> int { return (SP && t < pv ? padoff : toff) + t; };
+  const float* ux0 = a.u + (int64_t)c * a.Tp;
+  const float* ux1 = a.u + (int64_t)(D + c) * a.Tp;
+  const float* uv = a.u + (int64_t)(2 * D + c) * a.Tp;
+  const unsigned char* tok = TAB ? a.tok : nullptr;
   if (TAB) {
     if (tid < 3 * 17) {
       const int k3 = tid / 17, id = tid - 17 * k3;
@@ -282,9 +284,10 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
     Raw r;
     const int tc = t < t_last ? t : t_last;
     const int tl = tc >= 2 ? tc - 2 : 0;
+    const int sc = slot(tc), sl = slot(tl);
     if (TAB) {
-      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + tc);
-      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + tl);
+      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + sc);
+      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + sl);
       uint32_t ids = (t >= 2 ? lo16 : 0xFFFFu) | (hi16 << 16);
       if (t + 1 >= L) ids |= 0xFF000000u;
       if (t >= L) ids = 0xFFFFFFFFu;
@@ -292,8 +295,8 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
       r.hi = make_float2(0.f, 0.f);
       return r;
     }
-    const float2 lo = *reinterpret_cast<const float2*>(row + tl);
-    const float2 hi = *reinterpret_cast<const float2*>(row + tc);
+    const float2 lo = *reinterpret_cast<const float2*>(row + sl);
+    const float2 hi = *reinterpret_cast<const float2*>(row + sc);
     const bool in = t < L;
     r.lo = make_float2(in && t >= 2 ? lo.x : 0.f, in && t >= 2 ? lo.y : 0.f);
     r.hi = make_float2(in ? hi.x : 0.f, in && t + 1 < L ? hi.y : 0.f);
@@ -419,7 +422,7 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
       const int t = 2 * (tid + (j0 + u) * T);
       const v2f rv = V(s_me[(j0 + u) * PSTEP]);
       const v2f o = rv * v2f{inv_m, -inv_m} * sc_eval(0, r0[u]);
-      if (t < L) {
+      if (t < L && t >= pv) {  // (SP: own positions only)
         if (t + 1 < L) {
           *reinterpret_cast<float2*>(y + t) = F(o);
         } else {
@@ -447,24 +450,28 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
 constexpr int F15_LOGM = 15, F15_M = 1 << F15_LOGM, F15_N2 = 2048, F15_ROW = F15_N2 + F15_N2 / 16;  // padded row (float2)
 
 // short causal filter + gating helpers of one (read, channel) (the same arithmetic as hyena_fft_kernel's lambdas)
-template <bool TAB>
+template <bool TAB, bool SP>
 struct GateSrc {
   const float *ux0, *ux1, *uv;
   const unsigned char* tok;
   const float* s_tab;
   int L, t_last;
+  int toff, pv, padoff;  // SP: positions < pv (a multiple of 4) live in the shared [PAD] row at slot padoff + t
+  __device__ __forceinline__ int slot(int t) const { return (SP && t < pv ? padoff : toff) + t; }
   float sw_[3][3], sb_[3];
   struct Raw {
     float2 lo, hi;
   };
   __device__ __forceinline__ void init(const HyenaArgs& a, int r, int c, const float* s_tab_) {
-    const int64_t toff = a.toff[r];
+    toff = a.toff[r];
+    pv = SP ? a.pv[r] : 0;
+    padoff = SP ? a.padoff[r] : 0;
     L = a.ntok[r];
     t_last = L > 0 ? (L - 1) & ~1 : 0;
-    ux0 = a.u + (int64_t)c * a.Tp + toff;
-    ux1 = a.u + (int64_t)(a.D + c) * a.Tp + toff;
-    uv = a.u + (int64_t)(2 * a.D + c) * a.Tp + toff;
-    tok = TAB ? a.tok + toff : nullptr;
+    ux0 = a.u + (int64_t)c * a.Tp;
+    ux1 = a.u + (int64_t)(a.D + c) * a.Tp;
+    uv = a.u + (int64_t)(2 * a.D + c) * a.Tp;
+    tok = TAB ? a.tok : nullptr;
     s_tab = s_tab_;
 #pragma unroll
     for (int k3 = 0; k3 < 3; ++k3) {
@@ -477,9 +484,10 @@ struct GateSrc {
     Raw r;
     const int tc = t < t_last ? t : t_last;
     const int tl = tc >= 2 ? tc - 2 : 0;
+    const int sc = slot(tc), sl = slot(tl);
     if (TAB) {
-      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + tc);
-      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + tl);
+      const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(tok + sc);
+      const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(tok + sl);
       uint32_t ids = (t >= 2 ? lo16 : 0xFFFFu) | (hi16 << 16);
       if (t + 1 >= L) ids |= 0xFF000000u;
       if (t >= L) ids = 0xFFFFFFFFu;
@@ -487,8 +495,8 @@ struct GateSrc {
       r.hi = make_float2(0.f, 0.f);
       return r;
     }
-    const float2 lo = *reinterpret_cast<const float2*>(row + tl);
-    const float2 hi = *reinterpret_cast<const float2*>(row + tc);
+    const float2 lo = *reinterpret_cast<const float2*>(row + sl);
+    const float2 hi = *reinterpret_cast<const float2*>(row + sc);
     const bool in = t < L;
     r.lo = make_float2(in && t >= 2 ? lo.x : 0.f, in && t >= 2 ? lo.y : 0.f);
     r.hi = make_float2(in ? hi.x : 0.f, in && t + 1 < L ? hi.y : 0.f);
@@ -561,7 +569,7 @@ __device__ __forceinline__ void f15_forward_rows(float2* s0, float2* s1, int ka,
   fft_lds<11>(tid < 128 ? s0 : s1, tw, tid & 127);
 }
 
-template <bool TAB>
+template <bool TAB, bool SP>
 __global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int32_t* __restrict__ reads, const float2* __restrict__ tw,
                                                           const float2* __restrict__ spec, float2* __restrict__ scratch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw15[];
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int
     }
     __syncthreads();
   }
-  GateSrc<TAB> g;
+  GateSrc<TAB, SP> g;
   g.init(a, r, c, s_tab);
   int ka, kb;
   f15_rows(p, ka, kb);
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int
 }
 
 // second kernel: r[b + 2048 a] = sum_k1 scratch[k1][b] W16^(k1 a); y[t] = conv[t] * shortconv(x0)[t]
-template <bool TAB>
+template <bool TAB, bool SP>
 __global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
                                                               const float2* __restrict__ scratch) {
   __shared__ float s_tab[64];
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const
     }
     __syncthreads();
   }
-  GateSrc<TAB> g;
+  GateSrc<TAB, SP> g;
   g.init(a, r, c, s_tab);
   const int b = bblk * 256 + tid;
   const float2* in = scratch + ((int64_t)slot * a.D + c) * F15_M + b;
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const
 #pragma unroll
   for (int aa = 0; aa < 9; ++aa) {  // t = 2 (b + 2048 aa) < 32 770
     const int t = 2 * (b + F15_N2 * aa);
-    if (t < L) {
+    if (t < L && t >= g.pv) {  // (SP: own positions only)
       const v2f rv = V(u[bitrev(aa, 4)]);
       v2f conv = rv * v2f{inv_m, -inv_m};
       if (t == F15_M) {  // L = M + 1: the tap the M-tap spectrum leaves out, y[M] += k'[M] z[0]
@@ -743,13 +751,17 @@ int launch_filter_t(hipStream_t st, const float* kf, int64_t kf_stride, int kf_t
   return DC_OK;
 }
 
-template <int LOGM, bool TAB>
-int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+template <int LOGM, bool TAB, bool SP>
+int launch_fft_t2(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
   constexpr int T = (1 << LOGM) / 16;
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fft_kernel<LOGM, TAB>), fft_smem<LOGM>());
-  hipLaunchKernelGGL((hyena_fft_kernel<LOGM, TAB>), dim3(n_reads, a.D), dim3(T), fft_smem<LOGM>(), st, a, reads, tw, spec);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fft_kernel<LOGM, TAB, SP>), fft_smem<LOGM>());
+  hipLaunchKernelGGL((hyena_fft_kernel<LOGM, TAB, SP>), dim3(n_reads, a.D), dim3(T), fft_smem<LOGM>(), st, a, reads, tw, spec);
   DC_LAUNCH_CHECK();
   return DC_OK;
+}
+template <int LOGM, bool TAB>
+int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  return a.pv ? launch_fft_t2<LOGM, TAB, true>(st, a, reads, n_reads, tw, spec) : launch_fft_t2<LOGM, TAB, false>(st, a, reads, n_reads, tw, spec);
 }
 
 }  // namespace
@@ -792,15 +804,20 @@ int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads,
   const float2* s2 = reinterpret_cast<const float2*>(spec);
   float2* sc = reinterpret_cast<float2*>(scratch);
   const dim3 grid((unsigned)(8 * n_reads), (unsigned)a.D), block(256);
+#define DC_F15_LAUNCH(TAB, SP)                                                                                          \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((hyena_fft15_kernel<TAB, SP>), grid, block, f15_smem(), st, a, reads, t2, s2, sc);               \
+    DC_LAUNCH_CHECK();                                                                                                  \
+    hipLaunchKernelGGL((hyena_fft15_out_kernel<TAB, SP>), grid, block, 0, st, a, reads, (const float2*)sc);             \
+  } while (0)
   if (a.tok) {
-    hipLaunchKernelGGL(hyena_fft15_kernel<true>, grid, block, f15_smem(), st, a, reads, t2, s2, sc);
-    DC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hyena_fft15_out_kernel<true>, grid, block, 0, st, a, reads, (const float2*)sc);
+    if (a.pv) DC_F15_LAUNCH(true, true);
+    else DC_F15_LAUNCH(true, false);
   } else {
-    hipLaunchKernelGGL(hyena_fft15_kernel<false>, grid, block, f15_smem(), st, a, reads, t2, s2, sc);
-    DC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hyena_fft15_out_kernel<false>, grid, block, 0, st, a, reads, (const float2*)sc);
+    if (a.pv) DC_F15_LAUNCH(false, true);
+    else DC_F15_LAUNCH(false, false);
   }
+#undef DC_F15_LAUNCH
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

@@ -280,6 +280,30 @@ class HipModel:
             first.ctypes.data_as(C.POINTER(C.c_int32)), n_tokens.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(out)))
         return out
 
+    def forward_shared_prefix(self, input_ids, input_quals, first: np.ndarray, n_tokens: np.ndarray, n_pad: np.ndarray,
+                              pad_token_id: int = 4, out=None):
+        """forward_ragged(first, n_tokens) for rows that begin with n_pad[r] [PAD] tokens (quality 0), as the reference's
+        collator pads a batch (tokenizer.py:71-87): the pad runs of all rows go through the model once per launch
+        (`dc_forward_shared_prefix`).  Same logits, pad columns included."""
+        n, row_stride = input_ids.shape
+        first = np.ascontiguousarray(first, dtype=np.int32)
+        n_tokens = np.ascontiguousarray(n_tokens, dtype=np.int32)
+        n_pad = np.ascontiguousarray(n_pad, dtype=np.int32)
+        assert first.shape == n_tokens.shape == n_pad.shape == (n,)
+        if out is None:
+            out = torch.zeros((n, row_stride, self.cfg.num_class), dtype=torch.float32, device=input_ids.device)
+        i32p = C.POINTER(C.c_int32)
+        _lib.check(_lib.lib().dc_forward_shared_prefix(
+            self._h, _stream(), _ptr(input_ids), int(input_ids.dtype == torch.int64), _ptr(input_quals), n, row_stride,
+            first.ctypes.data_as(i32p), n_tokens.ctypes.data_as(i32p), n_pad.ctypes.data_as(i32p), int(pad_token_id), _ptr(out)))
+        return out
+
+    def prefix_violations(self) -> int:
+        """Declared pad positions of `forward_shared_prefix` launches that did not hold ([PAD], 0.0) (synchronises)."""
+        v = C.c_int32()
+        _lib.check(_lib.lib().dc_model_prefix_violations(self._h, _stream(), C.byref(v)))
+        return int(v.value)
+
     def head_forward(self, hidden: torch.Tensor, input_quals: torch.Tensor) -> torch.Tensor:
         """Diagnostic: final LayerNorm + head on a residual stream f32[B, L, d_model] -> logits f32[B, L, 2]."""
         assert hidden.dim() == 3 and hidden.shape[:2] == input_quals.shape and hidden.shape[2] == self.cfg.d_model

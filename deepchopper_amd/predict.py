@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .fastq import decode_names
-from .tokenizer import DEFAULT_MAX_LENGTH, check_read_status, encode_ids_int8
+from .tokenizer import DEFAULT_MAX_LENGTH, PAD_TOKEN_ID, check_read_status, encode_ids_int8
 
 
 @dataclass
@@ -70,6 +70,9 @@ class PredictPipeline:
         self.max_length = max_length
         self.smooth = smooth or SmoothParams()
         self._copy_stream = None
+        # reference_padding: rows share their [PAD] prefix (dc_forward_shared_prefix) instead of running it once per row;
+        # DC_SHARED_PREFIX=0 keeps the padded launches (A/B, parity tests)
+        self.shared_prefix = os.environ.get("DC_SHARED_PREFIX", "1") != "0"
 
     # ---- stage 1 ---------------------------------------------------------------------
     def tokenize(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, max_len_bases: int,
@@ -120,22 +123,32 @@ class PredictPipeline:
         tok = self.tokenize(seq, qual, offsets, max_len, pad_left=True, ids_i64=ids_i64, want_labels=want_labels)
         assert tok["input_ids"].shape[1] == row_stride
         sub_cols = None
-        if reference_padding and sub_sizes is not None and len(sub_sizes) > 1:
-            # tokens of a row as the reference's collator pads it: up to the longest read of ITS sub-batch
+        net = self.model.net
+        if reference_padding and not bool(np.all(ntok == row_stride)):
+            # tokens of a row as the reference's collator pads it: up to the longest read of ITS (sub-)batch
             sub_tok = np.empty(n, np.int32)
-            sub_cols = []
-            r0 = 0
-            for k in sub_sizes:
-                lb = int(ntok[r0: r0 + k].max())
-                sub_tok[r0: r0 + k] = lb
-                sub_cols.append(row_stride - lb)
-                r0 += k
-            assert r0 == n, "sub_sizes must add up to the batch"
-            logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], (row_stride - sub_tok).astype(np.int32), sub_tok)
+            if sub_sizes is not None and len(sub_sizes) > 1:
+                sub_cols = []
+                r0 = 0
+                for k in sub_sizes:
+                    lb = int(ntok[r0: r0 + k].max())
+                    sub_tok[r0: r0 + k] = lb
+                    sub_cols.append(row_stride - lb)
+                    r0 += k
+                assert r0 == n, "sub_sizes must add up to the batch"
+            else:
+                sub_tok[:] = row_stride
+            sub_first = (row_stride - sub_tok).astype(np.int32)
+            if self.shared_prefix:
+                # the pad runs of all rows go through the model once per launch (HyenaDNA is causal): same logits
+                logits = net.forward_shared_prefix(tok["input_ids"], tok["input_quals"], sub_first, sub_tok, sub_tok - ntok,
+                                                   pad_token_id=PAD_TOKEN_ID)
+            else:
+                logits = net.forward_ragged(tok["input_ids"], tok["input_quals"], sub_first, sub_tok)
         elif reference_padding or bool(np.all(ntok == row_stride)):
-            logits = self.model.net.forward(tok["input_ids"], tok["input_quals"])
+            logits = net.forward(tok["input_ids"], tok["input_quals"])
         else:
-            logits = self.model.net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
+            logits = net.forward_ragged(tok["input_ids"], tok["input_quals"], first, ntok)
         sp = self.smooth
         sm = ops.smooth_intervals_from_logits(logits, d_first, d_len, window=sp.window, min_interval=sp.min_interval,
                                               approved=sp.approved, want_labels=want_labels,

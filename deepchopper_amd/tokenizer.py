@@ -19,6 +19,7 @@ MAX_ID_LENGTH = 256
 IGNORE_INDEX = -100
 VOCAB = {"[CLS]": 0, "[SEP]": 1, "[BOS]": 2, "[MASK]": 3, "[PAD]": 4, "[RESERVED]": 5, "[UNK]": 6,
          "A": 7, "C": 8, "G": 9, "T": 10, "N": 11}
+PAD_TOKEN_ID = VOCAB["[PAD]"]  # what the collator pads `input_ids` with (tokenizer.py:71-87; src/smooth/utils.rs:6-25)
 
 
 def encode_ids_int8(read_id: str, truncated: bool, max_id_length: int = MAX_ID_LENGTH) -> np.ndarray:

@@ -238,6 +238,33 @@ int dc_forward_ragged(dc_model* m, void* stream, const void* d_input_ids, int32_
                       const float* d_input_quals, int32_t n_reads, int64_t row_stride,
                       const int32_t* h_first, const int32_t* h_n_tokens, float* d_logits);
 
+/* Reference batches without the cost of their padding.  The reference's collator left-pads every batch to its longest
+ * read with [PAD] (deepchopper/models/llm/tokenizer.py:71-87, `deepchopper predict -b 12`, deepchopper/cli.py:70) and the pad
+ * tokens run through the model like any other token (no attention mask), so a read's logits depend on how
+ * many pads stand in front of it -- dc_forward / dc_forward_ragged reproduce that by running every row at its padded
+ * length.  HyenaDNA is causal: what the model computes over a run of [PAD] at the head of a row is the same for every
+ * row.  This entry point computes it ONCE per launch: arguments as dc_forward_ragged, plus h_n_pad[r] = how many of row
+ * r's n_tokens[r] tokens, counted from first[r], are left padding -- the caller asserts that those positions hold
+ * (pad_token_id, quality 0.0), as the collator writes them.  Per launch one all-[PAD] row per long-convolution form in use
+ * stands for every row's pad run (rounded down to a multiple of 4; a row keeps the last <= 3 pads itself): embedding,
+ * every GEMM, the fused MLP and the head see sum(n_tokens - n_pad) + a few shared rows instead of sum(n_tokens) tokens;
+ * the long-convolution kernels read a row's positions in front of its own tokens from the shared row.
+ * Results are those of dc_forward_ragged(first, n_tokens) on the same buffers: bit for bit while every row takes a
+ * block-Toeplitz long convolution (<= fft threshold tokens), within fp32 rounding of the FFT forms above (whose circular
+ * transform lets later tokens reach the pad positions as rounding noise, in the reference too).  Logits are written
+ * for all n_tokens[r] positions of a row, pad columns included (copied from the shared row).
+ * The pad positions themselves are never read by the model; the copy pass checks them and counts violations of the
+ * contract (dc_model_prefix_violations).  Requires 0 <= h_n_pad[r] < h_n_tokens[r].  Host arrays as in dc_forward_ragged. */
+int dc_forward_shared_prefix(dc_model* m, void* stream, const void* d_input_ids, int32_t ids_i64,
+                             const float* d_input_quals, int32_t n_reads, int64_t row_stride,
+                             const int32_t* h_first, const int32_t* h_n_tokens, const int32_t* h_n_pad,
+                             int32_t pad_token_id, float* d_logits);
+
+/* Wavefronts of dc_forward_shared_prefix's copy pass that met a declared pad position not holding
+ * (pad_token_id, 0.0) since the last call; synchronises `stream`, resets the counter.  Non-zero = the caller broke the
+ * contract and the logits of that launch are not those of the padded batch. */
+int dc_model_prefix_violations(dc_model* m, void* stream, int32_t* count);
+
 /* Diagnostic: the tail of the forward alone -- final LayerNorm + TokenClassificationHead.forward
  * (deepchopper/models/llm/head.py:75-102) -- on a caller-supplied residual stream
  * d_hidden float[batch, seq_len, d_model] (the backbone's last hidden state BEFORE ln_f, token-major as the

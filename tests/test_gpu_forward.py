@@ -702,3 +702,124 @@ def test_fft_long_convolution_matches_toeplitz_and_oracle(env, L):
     finally:
         model.set_fft_threshold(2560)  # the shipped default (forward_api.hip: fft_min_tokens)
         model.set_profiling(False)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dc_forward_shared_prefix: the reference's left-padded batches with the [PAD] runs of all rows computed once per launch
+# ----------------------------------------------------------------------------------------------------------------
+def _padded_launch(rng, batches):
+    """`batches`: list of lists of read lengths in TOKENS (incl. [SEP]); every inner list is one reference batch, left-padded
+    to its longest read (deepchopper/models/llm/tokenizer.py:71-87); all batches share one dense [n, row_stride] launch as
+    `fastq.fuse_chunks` + `PredictPipeline.run_device_batch(sub_sizes=...)` lay them out.  Returns ids (uint8), quals,
+    first, n_tokens (= the padded length of the row's batch), n_pad."""
+    lens = np.array([x for b in batches for x in b], np.int32)
+    n, stride = len(lens), int(lens.max())
+    ids = np.full((n, stride), 4, np.uint8)
+    q = np.zeros((n, stride), np.float32)
+    ntok = np.empty(n, np.int32)
+    r = 0
+    for b in batches:
+        ntok[r: r + len(b)] = max(b)
+        r += len(b)
+    for r, L in enumerate(lens.tolist()):
+        ids[r, stride - L:] = rng.integers(7, 12, L)
+        ids[r, -1] = 1
+        qq = rng.integers(1, 41, L).astype(np.float32)
+        qq[-1] = 0
+        q[r, stride - L:] = qq / max(float(np.linalg.norm(qq)), 1e-12)
+    return ids, q, (stride - ntok).astype(np.int32), ntok, (ntok - lens).astype(np.int32)
+
+
+def _nanopore_lens(rng, n, cap):
+    return np.clip(np.exp(np.log(900.0) + 0.75 * rng.standard_normal(n)), 100, cap).astype(np.int32) + 1
+
+
+SHARED_PREFIX_CASES = {
+    # name: (batches builder, every row on a block-Toeplitz form -> bit-identical)
+    "uniform_500_1500": (lambda rng: [list(rng.integers(501, 1502, 12)) for _ in range(6)], True),
+    "nanopore_like_capped_2500": (lambda rng: [list(_nanopore_lens(rng, 12, 2500)) for _ in range(6)], True),
+    # pad runs = 0 (the longest row), 1, 2, 3 (owned by the row in full), 4, 5, 6, 7 (mod 4 = 0..3), 31, 32, 33, 63, 95 (mod 32)
+    "pad_run_residues": (lambda rng: [[700 - p for p in (0, 1, 2, 3, 4, 5, 6, 7, 31, 32, 33, 63, 95, 127, 640, 697)]], True),
+    "single_row_batches_and_no_padding": (lambda rng: [[300], [411, 411], [257, 100, 31, 2]], True),
+    "padded_length_above_2560": (lambda rng: [[3100, 900, 2800, 150, 2561 - 4, 3099], [400, 380, 210]], False),
+    "nanopore_like": (lambda rng: [list(_nanopore_lens(rng, 12, 12000)) for _ in range(4)], False),
+    "padded_length_above_16384": (lambda rng: [[17000, 500, 16385 - 8, 9000], [3000, 2999, 64]], False),
+}
+
+
+@pytest.mark.parametrize("case", list(SHARED_PREFIX_CASES))
+def test_shared_prefix_equals_the_padded_launch(env, case):
+    """rows `[PAD] x p ++ read` (quality 0 on the pads) through dc_forward_shared_prefix give the
+    logits of dc_forward_ragged on the whole padded rows -- over the real tokens AND over the pad columns -- bit for
+    bit while every row takes a block-Toeplitz long convolution, <= 2e-4 (the parity tolerance) where rows take an FFT
+    form, in every GEMM mode; and the compact launch really is compact (token slots of the GEMMs)."""
+    torch, ops, sd, model = env
+    build, exact = SHARED_PREFIX_CASES[case]
+    rng = np.random.default_rng(len(case))
+    ids, q, first, ntok, npad = _padded_launch(rng, build(rng))
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    padded = model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()
+    model.set_profiling(True)
+    model.profile_reset()
+    try:
+        shared = model.forward_shared_prefix(d_ids, d_q, first, ntok, npad).cpu().numpy()
+        stages = model.profile()
+    finally:
+        model.set_profiling(False)
+    assert model.prefix_violations() == 0
+    assert np.isfinite(shared).all()
+    mask = np.zeros(ids.shape, bool)
+    for r in range(len(ntok)):
+        mask[r, first[r]: first[r] + ntok[r]] = True
+    assert np.array_equal(shared[~mask], padded[~mask])  # (both leave the positions outside the rows untouched: zeros)
+    d = np.abs(shared - padded)[mask]
+    if exact:
+        assert stages.get("hyena_fft", (0, 0))[1] == 0 and stages.get("hyena_fft15", (0, 0))[1] == 0, stages
+        assert d.max() == 0.0, f"{case} ({model.gemm_mode}): max |d| = {d.max():.3e}, must be bit-identical"
+    else:
+        assert stages.get("hyena_fft", (0, 0))[1] + stages.get("hyena_fft15", (0, 0))[1] > 0, stages
+        assert d.max() <= ATOL, f"{case} ({model.gemm_mode}): max |d| = {d.max():.3e}"
+    if npad.max() >= 4:
+        assert stages.get("pad_fill", (0, 0))[1] == 1, stages
+    # same entry point with int64 ids (the `.pt` wire format's dtype)
+    shared64 = model.forward_shared_prefix(ops.to_device(ids.astype(np.int64)), d_q, first, ntok, npad).cpu().numpy()
+    assert np.array_equal(shared64, shared)
+
+
+def test_shared_prefix_matches_batched_oracle(env):
+    """... and against the oracle run on the left-padded batches themselves (what the reference computes)."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(314)
+    batches = [[400, 130, 397, 262], [95, 333, 120], [2700, 610, 1200]]
+    ids, q, first, ntok, npad = _padded_launch(rng, batches)
+    out = model.forward_shared_prefix(ops.to_device(ids), ops.to_device(q), first, ntok, npad).cpu().numpy()
+    r = 0
+    for b in batches:
+        c0 = ids.shape[1] - max(b)
+        ref = fr.forward(sd, ids[r: r + len(b), c0:].astype(np.int64), q[r: r + len(b), c0:]).numpy()
+        _check(out[r: r + len(b), c0:], ref)
+        r += len(b)
+
+
+def test_shared_prefix_contract_violation_is_counted(env):
+    """The pad positions are never read by the model: a caller that declares a pad run over tokens that are not
+    ([PAD], quality 0) gets a count, not silence."""
+    torch, ops, sd, model = env
+    rng = np.random.default_rng(2)
+    ids, q, first, ntok, npad = _padded_launch(rng, [[300, 120, 200]])
+    assert model.prefix_violations() == 0
+    model.forward_shared_prefix(ops.to_device(ids), ops.to_device(q), first, ntok, npad)
+    assert model.prefix_violations() == 0
+    bad = ids.copy()
+    bad[1, first[1] + 17] = 9
+    model.forward_shared_prefix(ops.to_device(bad), ops.to_device(q), first, ntok, npad)
+    assert model.prefix_violations() > 0
+    assert model.prefix_violations() == 0  # (reading resets the counter)
+    badq = q.copy()
+    badq[2, first[2] + 40] = 0.25
+    model.forward_shared_prefix(ops.to_device(ids), ops.to_device(badq), first, ntok, npad)
+    assert model.prefix_violations() > 0
+    with pytest.raises(Exception, match="pad run must be shorter"):
+        model.forward_shared_prefix(ops.to_device(ids), ops.to_device(q), first, ntok, ntok)

@@ -320,23 +320,34 @@ def file_e2e_leg(pipe, sd, n_reads: int, read_len: int, batch: int, check_reads:
 # ------------------------------------------------------------------------------------------------------------
 # the reference's default batching (-b 12)
 # ------------------------------------------------------------------------------------------------------------
-def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000) -> dict:
+def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "uniform") -> dict:
     """FASTQ file -> batches of 12 as the reference's DataLoader forms them (deepchopper/cli.py:70) -> left-padded per batch,
     pad tokens through the model -> logits + labels + intervals on the host; reference batches share GPU
-    launches (`fastq.fuse_chunks`), each with its own padding.  Mixed lengths around `read_len` so that the padding is real.
+    launches (`fastq.fuse_chunks`), each with its own padding.  mix = "uniform": log-uniform lengths read_len / 2 ... 3 read_len / 2;
+    "nanopore": config 5's direct-RNA-like length mix (`synth.synth_nanopore_like`: log-normal, median 900, up to 30 kb).
+    `padded_over_real_tokens` = the tokens the reference's batches hold / the tokens of the reads themselves.
     Check: the first batch against the oracle run on that batch of 12 (logits <= 1e-3, labels, intervals)."""
     import torch
 
     from deepchopper_amd import synth
     from deepchopper_amd.fastq import FastqReader, fuse_chunks
 
-    seqs, quals, ids = synth.synth_reads_mixed(n_reads, read_len // 2, read_len + read_len // 2, seed=77)
-    bases = sum(len(x) for x in seqs)
+    if mix == "nanopore":
+        heads, seqs, quals = synth.synth_nanopore_like(n_reads, seed=77, gate=b"A")  # (synthetic weights: no token gate to plant for)
+        ids = [h.split(b" ")[0].decode() for h in heads]
+        text = synth.fastq_text(heads, seqs, quals)
+    else:
+        seqs, quals, ids = synth.synth_reads_mixed(n_reads, read_len // 2, read_len + read_len // 2, seed=77)
+        text = synth.to_fastq(seqs, quals, ids)
+    lens = np.array([len(x) for x in seqs], np.int64)
+    bases = int(lens.sum())
+    padded = sum(int(lens[i: i + 12].max() + 1) * len(lens[i: i + 12]) for i in range(0, n_reads, 12))
     tmp = tempfile.mkdtemp(prefix="dc_ref_")
     path = os.path.join(tmp, "reads.fq")
     try:
         with open(path, "wb") as fh:
-            fh.write(synth.to_fastq(seqs, quals, ids))
+            fh.write(text)
+        del text
 
         def run(limit=None):
             n = 0
@@ -364,8 +375,12 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000) -> dict:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"workload": "the reference's default batching: FASTQ file -> batches of 12 (left-padded per batch, pad tokens through the "
                        "model) -> logits + labels + intervals on the host; batches fused into shared launches, each with its own padding",
+           "lengths": "log-uniform %d-%d bp" % (read_len // 2, read_len + read_len // 2) if mix != "nanopore" else
+                      "nanopore-like (log-normal, median 900 bp, sigma 0.75, 100 bp - 30 kb)",
            "value": round(n / dt, 1), "unit": "reads/s", "Mbases_per_s": round(bases / dt / 1e6, 2), "reads": n, "seconds": round(dt, 3),
-           "mean_bp": round(bases / n_reads, 1)}
+           "mean_bp": round(bases / n_reads, 1), "max_bp": int(lens.max()),
+           "padded_over_real_tokens": round(padded / float(bases + n_reads), 3),
+           "shared_pad_prefix": bool(getattr(pipe, "shared_prefix", False))}
     from oracle import dc_oracle as o
     from oracle import forward_ref as fr
 
