@@ -469,6 +469,7 @@ def main():
                 configs["c4_mixed"] = leg(bench_legs.mixed_leg, pipe, sd, args.c4_reads)
             if "c5" in legs:
                 configs["c5_gz_chop"] = leg(bench_legs.gz_chop_leg, args.c5_reads, threads=4)
+                configs["c5_gz_chop_refbatch"] = leg(bench_legs.gz_chop_leg, args.c5_reads // 2, threads=4, reference_batch=12)
             if "ref" in legs:
                 configs["reference_b12"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000)
                 configs["reference_b12_nanopore"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000, mix="nanopore")

@@ -145,18 +145,31 @@ def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_
 
 
 def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all", output_chopped_seqs: bool = False,
-                        on_batch=None) -> tuple[int, int]:
+                        on_batch=None, reference_padding: bool = False, mark_sub_batches: bool = False) -> tuple[int, int]:
     """The fused flow on an open writer: every chunk goes FASTQ bytes -> tokenise -> forward -> smoothing ->
     intervals on the GPU, then gating + splitting + BGZF on the host library.  Chunks must come from a reader
-    opened with full_header=True.  Returns (reads predicted, records written)."""
+    opened with full_header=True.  Returns (reads predicted, records written).
+
+    reference_padding: the chunks are the reference's batches (`predict -b`, deepchopper/cli.py:70), alone or fused into
+    shared launches (`fastq.fuse_chunks`, `sub_sizes`): every batch is left-padded to its longest read and the pad tokens
+    count as the reference's collator and model make them count -- the predictions, and so the chopped
+    records, are those of the reference's two commands `predict` -> `chop` (src/bin/predict.rs:130-192), without the
+    28 B/token `.pt` files in between.  mark_sub_batches: end a BGZF block behind every original batch instead of behind
+    every launch (workers of a run whose batches were dealt round-robin: the parent splices batch by batch)."""
     params = chop_params(pipe.smooth, chop_type, output_chopped_seqs)
     n_reads = n_out = 0
-    for res in pipe.predict_stream(chunks, want_labels=False, borrow=True, want_names=False):
+    for res in pipe.predict_stream(chunks, want_labels=False, borrow=True, want_names=False, reference_padding=reference_padding):
         n = int(res["lengths"].shape[0])
-        n_out += writer.chop_write_chunk(params, n, res["headers"], res["header_offsets"], res["name_len"], res["seq"],
-                                         res["qual"], res["in_offsets"], res["pred_len"], res["n_intervals"],
-                                         res["intervals"], res["n_keep"], res["keep"])
-        writer.mark()  # a chunk's records end their BGZF block: per-GPU parts can be spliced in input order
+        subs = res.get("sub_sizes") if mark_sub_batches else None
+        r0 = 0
+        for k in (subs or [n]):  # (offsets are absolute into the chunk's packed buffers: a row range is a view of the per-read arrays)
+            nl = res["name_len"]
+            n_out += writer.chop_write_chunk(params, k, res["headers"], res["header_offsets"][r0:], None if nl is None else nl[r0:],
+                                             res["seq"], res["qual"], res["in_offsets"][r0:], res["pred_len"][r0:],
+                                             res["n_intervals"][r0:], res["intervals"][r0:], res["n_keep"][r0:], res["keep"][r0:])
+            writer.mark()  # a chunk's records end their BGZF block: per-GPU parts can be spliced in input order
+            r0 += k
+        assert r0 == n
         n_reads += n
         if on_batch is not None:
             on_batch(res)
@@ -165,8 +178,13 @@ def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all"
 
 def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | None = None, threads: int = 2,
                  output_chopped_seqs: bool = False, max_reads: int = 8192, max_tokens: int = 2_000_000,
-                 chunks=None, level: int = 6, part_path: str | None = None):
+                 chunks=None, level: int = 6, part_path: str | None = None, reference_batch: int | None = None,
+                 mark_sub_batches: bool = False):
     """`deepchopper predict` + `deepchopper chop` as one streaming pass (no `.pt` files).
+
+    reference_batch = B: the reads run in the reference's batches of B (`predict -b B`: consecutive reads, left-padded per
+    batch, pad tokens through the model), fused into launches of at most `max_reads` reads / `max_tokens` tokens; `chunks`,
+    when given, must then be those batches (reader chunks of B reads).  Default: every read at its own length.
 
     Output naming and the temp-file-then-rename protocol are the chop binary's (predict.rs:252-366).  With
     `part_path` (multi-GPU workers) the records go to that file instead and nothing is renamed: the parent
@@ -177,12 +195,23 @@ def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | Non
     try:
         fh = BgzfWriter(tmp, threads=threads, level=level)
         with fh:
+            ref = reference_batch is not None
+
+            def batches(src):
+                if not ref:
+                    return src
+                from .fastq import fuse_chunks
+
+                return fuse_chunks(src, max_reads, max_tokens, padded=not getattr(pipe, "shared_prefix", False))
+
             if chunks is None:
                 with FastqReader(fq, full_header=True) as rd:
-                    n_reads, n_out = predict_chop_stream(pipe, rd.chunks(max_reads, max_tokens), fh, chop_type,
-                                                         output_chopped_seqs)
+                    src = rd.chunks(reference_batch, 1 << 30) if ref else rd.chunks(max_reads, max_tokens)
+                    n_reads, n_out = predict_chop_stream(pipe, batches(src), fh, chop_type, output_chopped_seqs,
+                                                         reference_padding=ref, mark_sub_batches=mark_sub_batches)
             else:
-                n_reads, n_out = predict_chop_stream(pipe, chunks, fh, chop_type, output_chopped_seqs)
+                n_reads, n_out = predict_chop_stream(pipe, batches(chunks), fh, chop_type, output_chopped_seqs,
+                                                     reference_padding=ref, mark_sub_batches=mark_sub_batches)
         LAST_WRITER_STATS.update({"deflate_cpu_s": fh.deflate_cpu_s, "bgzf_bytes": fh.data_bytes, "threads": threads})
         if part_path:  # the writer is closed: the chunk offsets are known
             write_part_index(part_path, fh)

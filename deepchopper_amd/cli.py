@@ -75,7 +75,7 @@ def _smooth_params(args):
 
 
 def _chunk_limits(args, world: int) -> tuple[int, int]:
-    if args.native or args.chop:
+    if args.native or (args.chop and not args.reference_batching):
         return args.max_reads, args.max_tokens  # zero-padding batches bounded by a token budget (config 4)
     return args.batch_size // world, 1 << 30    # reference batches: per-device reads per step, left-padded
 
@@ -271,9 +271,17 @@ def _predict(args, argv: list[str]) -> int:
             nonlocal n_batches
             n_batches += 1
 
+        # --reference-batching: the reader chunks are the reference's batches (-b reads per device); they share launches of
+        # --max-reads / --max-tokens.  Where the chunks were dealt round-robin (one gzip stream, --max-sample) the parts are
+        # spliced batch by batch, so every batch ends its own BGZF block
+        ref_kw = {"max_reads": args.max_reads, "max_tokens": args.max_tokens}
+        if args.reference_batching:
+            dealt_in = args.chunk_fd is not None or (world > 1 and (
+                check_compressed_type(str(data_path)) not in ("Uncompress", "Bgzip") or args.max_sample is not None))
+            ref_kw.update({"reference_batch": max_reads, "mark_sub_batches": dealt_in})
         if args.part_path:  # worker of a multi-GPU run: the parent splices the parts and names the result
             _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
-                                                 args.ocq, chunks=chunks, part_path=args.part_path)
+                                                 args.ocq, chunks=chunks, part_path=args.part_path, **ref_kw)
         elif world > 1:  # external launcher (torch.distributed.run): parts on a name all ranks can derive, rank 0 merges
             from .chop import _temp_name
 
@@ -281,12 +289,12 @@ def _predict(args, argv: list[str]) -> int:
                                 f".deepchopper_temp_job{os.environ.get('MASTER_PORT', '0')}.fq.gz")
             parts = [f"{base}.rank{r}" for r in range(world)]
             _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
-                                                 args.ocq, chunks=chunks, part_path=parts[rank])
+                                                 args.ocq, chunks=chunks, part_path=parts[rank], **ref_kw)
             dealt = check_compressed_type(str(data_path)) not in ("Uncompress", "Bgzip") or args.max_sample is not None
             _merge_under_external_launcher(args, rank, world, parts, n_reads, n_records, dealt)
         else:
             final, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
-                                                     args.ocq, chunks=chunks)
+                                                     args.ocq, chunks=chunks, **ref_kw)
             print(final)
     else:
         os.makedirs(out_dir / "0", exist_ok=True)
@@ -306,7 +314,9 @@ def _predict(args, argv: list[str]) -> int:
                 # fifth of the chip, a fused launch all of it; every batch still gets its own `.pt` file
                 from .fastq import fuse_chunks
 
-                chunks = fuse_chunks(chunks, max_reads=args.max_reads, max_bases=args.max_tokens // 2)  # (padding inflates bases into tokens)
+                # (--max-tokens budgets what a launch runs through the GEMMs: the reads' own tokens when the [PAD] runs are
+                #  shared, the padded rows otherwise)
+                chunks = fuse_chunks(chunks, max_reads=args.max_reads, max_tokens=args.max_tokens, padded=not pipe.shared_prefix)
             for res in pipe.predict_stream(chunks, reference_padding=not args.native, ids_i64=not args.no_pt,
                                            want_labels=not args.no_pt):
                 if tsv is not None:
@@ -392,6 +402,10 @@ def main(argv=None) -> int:
     p.add_argument("--max-reads", type=int, default=8192, help="read cap per --native / --chop batch (-b applies to reference batches)")
     p.add_argument("--chop", action="store_true", help="fused predict -> chop: write the chopped reads as BGZF FASTQ, no .pt files")
     p.add_argument("--chop-output", default=None, help="output prefix of --chop (default: the FASTQ's stem, as deepchopper chop)")
+    p.add_argument("--reference-batching", action="store_true",
+                   help="with --chop: run the reads in the reference's batches (-b reads, left-padded per batch, pad tokens through "
+                        "the model) so that the chopped reads are those of the reference's `predict` + `chop`; default: every read "
+                        "at its own length (= the reference at -b 1)")
     _add_chop_options(p, prefix_output=False, threads=4)
     p.add_argument("--report-json", default=None, help=argparse.SUPPRESS)          # host-budget accounting of the run
     p.add_argument("--chunk-fd", type=int, default=None, help=argparse.SUPPRESS)   # worker: chunks come from the parent

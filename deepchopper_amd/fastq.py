@@ -59,16 +59,18 @@ class FastqChunk:
             yield name, s[o[i]: o[i + 1]], q[o[i]: o[i + 1]]
 
 
-def fuse_chunks(chunks, max_reads: int, max_bases: int):
-    """Concatenate consecutive chunks (copies) into larger ones of at most `max_reads` reads / `max_bases` bases, remembering
+def fuse_chunks(chunks, max_reads: int, max_tokens: int, padded: bool = False):
+    """Concatenate consecutive chunks (copies) into larger ones of at most `max_reads` reads / `max_tokens` tokens, remembering
     the original sizes in `sub_sizes`.  For the reference-compatible `predict -b 12`: every reader chunk is one batch of the
     reference's DataLoader; fused, many of them share ONE GPU launch while each keeps its own left padding (and its own
-    `.pt` file).  A chunk that alone exceeds the limits is passed through on its own."""
+    `.pt` file).  A chunk's tokens: its reads' bases + one [SEP] each -- what a launch runs through the GEMMs when the
+    [PAD] runs are shared (`dc_forward_shared_prefix`) -- or, with `padded`, reads x (longest read + 1): what the
+    left-padded rows hold.  A chunk that alone exceeds the limits is passed through on its own."""
     pend: list[FastqChunk] = []
-    n = nb = 0
+    n = nt = 0
 
     def flush():
-        nonlocal pend, n, nb
+        nonlocal pend, n, nt
         if not pend:
             return None
         offs = np.zeros(n + 1, np.int64)
@@ -83,17 +85,18 @@ def fuse_chunks(chunks, max_reads: int, max_bases: int):
         names = np.concatenate([c._names[: int(c._name_offsets[c.n])] for c in pend])
         nlen = None if pend[0]._name_len is None else np.concatenate([c._name_len[: c.n] for c in pend])
         out = FastqChunk(n, seq, qual, offs, names, noffs, nlen, sub_sizes=[c.n for c in pend])
-        pend, n, nb = [], 0, 0
+        pend, n, nt = [], 0, 0
         return out
 
     for c in chunks:
         cb = int(c.offsets[c.n])
-        if pend and (n + c.n > max_reads or nb + cb > max_bases):
+        ct = c.n * (int(np.diff(c.offsets[: c.n + 1]).max()) + 1) if padded and c.n else cb + c.n
+        if pend and (n + c.n > max_reads or nt + ct > max_tokens):
             yield flush()
         pend.append(FastqChunk(c.n, c.seq[:cb].copy(), c.qual[:cb].copy(), c.offsets[: c.n + 1].copy(),
                                c._names[: int(c._name_offsets[c.n])].copy(), c._name_offsets[: c.n + 1].copy(),
                                None if c._name_len is None else c._name_len[: c.n].copy()))
-        n, nb = n + c.n, nb + cb
+        n, nt = n + c.n, nt + ct
     last = flush()
     if last is not None:
         yield last

@@ -301,13 +301,27 @@ def test_fuse_chunks_keeps_every_read_and_the_batch_boundaries(tmp_path):
     fq.write_bytes(synth.fastq_text([i.encode() + b" ch=%d" % k for k, i in enumerate(ids)], seqs, quals))
     for full in (False, True):
         with FastqReader(str(fq), full_header=full) as rd:
-            fused = list(fuse_chunks(rd.chunks(12, 1 << 30), max_reads=60, max_bases=20000))
+            fused = list(fuse_chunks(rd.chunks(12, 1 << 30), max_reads=60, max_tokens=20000))
         assert sum(c.n for c in fused) == 103 and len(fused) >= 2
         sizes = [k for c in fused for k in c.sub_sizes]
         assert sizes == [12] * 8 + [7] and all(sum(c.sub_sizes) == c.n for c in fused)
-        assert all(c.n <= 60 and (int(c.offsets[c.n]) <= 20000 or len(c.sub_sizes) == 1) for c in fused)
+        assert all(c.n <= 60 and (int(c.offsets[c.n]) + c.n <= 20000 or len(c.sub_sizes) == 1) for c in fused)
         got = [r for c in fused for r in c.records()]
         assert [g[0] for g in got] == ids and [g[1] for g in got] == seqs and [g[2] for g in got] == quals
     with FastqReader(str(fq)) as rd:  # a chunk larger than the limits passes on its own
-        big = list(fuse_chunks(rd.chunks(50, 1 << 30), max_reads=10, max_bases=100))
+        big = list(fuse_chunks(rd.chunks(50, 1 << 30), max_reads=10, max_tokens=100))
     assert [c.sub_sizes for c in big] == [[50], [50], [3]]
+    # `padded`: a batch counts reads x (its longest read + 1) tokens -- what its left-padded rows hold
+    with FastqReader(str(fq)) as rd:
+        batches = [(c.n, int(np.diff(c.offsets[: c.n + 1]).max()) + 1) for c in rd.chunks(12, 1 << 30)]
+    with FastqReader(str(fq)) as rd:
+        pad = list(fuse_chunks(rd.chunks(12, 1 << 30), max_reads=1000, max_tokens=25000, padded=True))
+    assert sum(c.n for c in pad) == 103
+    b = 0
+    for c in pad:
+        held = sum(n * L for n, L in batches[b: b + len(c.sub_sizes)])
+        assert held <= 25000 or len(c.sub_sizes) == 1
+        if b + len(c.sub_sizes) < len(batches):  # ... and the next batch would not have fitted
+            n, L = batches[b + len(c.sub_sizes)]
+            assert held + n * L > 25000
+        b += len(c.sub_sizes)

@@ -652,7 +652,7 @@ def test_fused_reference_batches_write_the_files_of_separate_launches(env, tmp_p
         with FastqReader(str(fq)) as rd:
             chunks = rd.chunks(12, 1 << 30)
             if fused:
-                chunks = fuse_chunks(chunks, max_reads=40, max_bases=1 << 30)  # 3 + 3 batches per launch
+                chunks = fuse_chunks(chunks, max_reads=40, max_tokens=1 << 30)  # 3 + 3 batches per launch
             for res in pipe.predict_stream(chunks, reference_padding=True, ids_i64=True):
                 subs = res["sub_sizes"] or [len(res["names"])]
                 cols = res["sub_cols"] or [0] * len(subs)
@@ -678,3 +678,91 @@ def test_fused_reference_batches_write_the_files_of_separate_launches(env, tmp_p
     ref = _oracle_reads(sd, ids[:12], seqs[:12], quals[:12], batch=12)
     y = torch.load(b / "0_0.pt", weights_only=True)
     assert np.abs(y["prediction"].numpy() - ref[ids[0]][1]).max() < 2e-4
+
+
+@pytest.mark.parametrize("chop_type,ocq", [("all", False), ("terminal", False), ("internal", False), ("all", True)])
+def test_fused_predict_chop_with_reference_batching_equals_predict_then_chop(env, tmp_path, chop_type, ocq):
+    """`predict --chop --reference-batching` = the reference's DEFAULT two commands -- `predict -b 12`
+    (left-padded batches of 12 whose pad tokens run through the model, deepchopper/cli.py:66-198, tokenizer.py:71-87) then
+    `chop` over the `.pt` files (src/bin/predict.rs:130-192) -- as one streaming pass without the 28 B/token files.
+    RANDOM weights: the logits of a read depend on the pads in front of it (token-gated weights would not notice), so the
+    native zero-padding flow gives other predictions; a permissive chop policy so that reads really are chopped.
+    Reads stay below the FFT threshold: every row takes a block-Toeplitz long convolution, whose results do not depend on
+    what else shares the launch -- the fused launches and the one-launch-per-batch `.pt` route agree bit for bit, so the
+    files must agree byte for byte (decompressed)."""
+    import gzip
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.chop import chop, predict_chop
+    from deepchopper_amd.fastq import FastqReader
+    from deepchopper_amd.predict import PredictPipeline, SmoothParams, write_pt_batch
+
+    torch, sd, pipe0 = env
+    sp = SmoothParams(window=21, min_interval=5, approved=40, max_process_intervals=40)
+    pipe = PredictPipeline(pipe0.model, smooth=sp)
+    assert pipe.shared_prefix
+    seqs, quals, ids = synth.synth_reads_mixed(79, 150, 2400, seed=8)  # 6 batches of 12 + one of 7
+    heads = [i.encode() + b" ch=%d" % k for k, i in enumerate(ids)]
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.fastq_text(heads, seqs, quals))
+    os.chdir(tmp_path)
+    tag = f"{chop_type}_{int(ocq)}"
+    final, n_reads, n_out = predict_chop(str(fq), pipe, chop_type, output_prefix=str(tmp_path / f"ref_{tag}"), output_chopped_seqs=ocq,
+                                         max_reads=40, max_tokens=1 << 30, reference_batch=12)
+    assert n_reads == 79
+    got = gzip.open(final, "rb").read()
+    # the reference's route: one launch and one `.pt` per batch of 12, then chop
+    pdir = tmp_path / f"pred_{tag}" / "0"
+    with FastqReader(str(fq)) as rd:
+        for b, res in enumerate(pipe.predict_stream(rd.chunks(12, 1 << 30), reference_padding=True, ids_i64=True)):
+            write_pt_batch(str(pdir / f"0_{b}.pt"), res["device"], res["names"])
+    assert b == 6
+    via_pt = chop([str(pdir)], str(fq), sp, chop_type, output_prefix=str(tmp_path / f"pt_{tag}"), output_chopped_seqs=ocq)
+    want = gzip.open(via_pt, "rb").read()
+    assert got == want
+    assert os.path.basename(final) == os.path.basename(via_pt).replace("pt_", "ref_")  # same {n}pd.{m}record counts
+    # ... the same without the shared [PAD] rows (every row's pads through the model, as rounds 1-4 ran it)
+    padded = PredictPipeline(pipe0.model, smooth=sp)
+    padded.shared_prefix = False
+    f2, _, _ = predict_chop(str(fq), padded, chop_type, output_prefix=str(tmp_path / f"pad_{tag}"), output_chopped_seqs=ocq,
+                            max_reads=40, max_tokens=1 << 30, reference_batch=12)
+    assert gzip.open(f2, "rb").read() == want
+    # ... and the flag does something: every read at its own length predicts (and chops) differently
+    f3, n3, _ = predict_chop(str(fq), pipe, chop_type, output_prefix=str(tmp_path / f"nat_{tag}"), output_chopped_seqs=ocq)
+    native = gzip.open(f3, "rb").read()
+    assert n3 == 79 and native != want
+    if chop_type == "all" and not ocq:
+        recs = want.split(b"\n")[0::4]
+        assert sum(1 for r in recs if r.endswith(b"|T") or r.endswith(b"|I")) > 20  # reads really were chopped
+
+
+def test_cli_predict_chop_reference_batching(env, tmp_path):
+    """The command line of the above: `deepchopper predict reads.fq --chop --reference-batching -b 12` against the two
+    commands `deepchopper predict reads.fq -b 12 -o pred` + `deepchopper chop pred/0 reads.fq`."""
+    import gzip
+
+    from deepchopper_amd import synth
+    from deepchopper_amd.weights import save_state_dict
+
+    torch, sd, _ = env
+    seqs, quals, ids = synth.synth_reads_mixed(50, 150, 1800, seed=31)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    ck = tmp_path / "ckpt"
+    save_state_dict(sd, str(ck / "model.safetensors"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    policy = ["--min-interval-size", "5", "--approved-intervals", "40", "--max-process-intervals", "40"]
+
+    def run(*argv):
+        p = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", *argv], cwd=tmp_path, env=envv, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
+
+    one = run("predict", str(fq), "-g", "1", "-m", str(ck), "-b", "12", "--chop", "--reference-batching", "--chop-output", "one", *policy)
+    run("predict", str(fq), "-g", "1", "-m", str(ck), "-b", "12", "-o", "pred")
+    two = run("chop", "pred/0", str(fq), "-o", "two", *policy)
+    a, b = gzip.open(tmp_path / one, "rb").read(), gzip.open(tmp_path / two, "rb").read()
+    assert a == b and a.count(b"\n") >= 4 * 50
+    nat = run("predict", str(fq), "-g", "1", "-m", str(ck), "--chop", "--chop-output", "nat", *policy)
+    assert gzip.open(tmp_path / nat, "rb").read() != a

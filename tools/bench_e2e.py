@@ -196,7 +196,7 @@ def ref_batch_bench(args):
         with FastqReader(path) as rd:
             chunks = rd.chunks(args.ref_batch, 1 << 26)
             if name == "fused":  # what `deepchopper predict -b 12` does since round 4: reference batches share launches
-                chunks = fuse_chunks(chunks, max_reads=8192, max_bases=1_000_000)
+                chunks = fuse_chunks(chunks, max_reads=8192, max_tokens=2_000_000, padded=not pipe.shared_prefix)
             for res in pipe.predict_stream(chunks, reference_padding=True, ids_i64=True, serialize=ser):
                 n += len(res["names"])
                 if name == "warmup" and n >= 50 * args.ref_batch:

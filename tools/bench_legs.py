@@ -168,11 +168,13 @@ def _count_output(path: str) -> dict:
             "bases_out": bases}
 
 
-def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24) -> dict:
+def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24, reference_batch: int | None = None) -> dict:
     """Nanopore-like reads (log-normal lengths, ONT headers, adapters planted as runs of the base the token-gated
     weights label 1) -> gzip file -> `predict_chop` (the body of `deepchopper predict --chop`) -> chopped BGZF.
     Checks: (1) the head of the output file equals, byte for byte, what the oracle's forward + `chop_read` emit for the
-    first `check_reads` reads; (2) the whole file parses and its record count is the one the driver reported."""
+    first `check_reads` reads; (2) the whole file parses and its record count is the one the driver reported.
+    reference_batch = 12: `predict --chop --reference-batching` -- the reads run in the reference's left-padded batches of 12
+    (pad tokens through the model, shared per launch), the oracle of check (1) runs those batches."""
     import torch
 
     from deepchopper_amd import synth
@@ -204,16 +206,19 @@ def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24) -> dict:
         h, s, q = synth.synth_nanopore_like(20_000, seed=7)
         with open(warm, "wb") as fh:
             fh.write(synth.fastq_text(h, s, q))
-        final, _, _ = predict_chop(warm, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000)
+        final, _, _ = predict_chop(warm, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000, reference_batch=reference_batch)
         os.remove(final)
         os.remove(warm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        final, n_in, n_out = predict_chop(path, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000)
+        final, n_in, n_out = predict_chop(path, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000, reference_batch=reference_batch)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out = {"workload": "configs[4] flow on one GPU: nanopore-like reads (log-normal lengths, ONT headers, adapters planted), plain "
-                           ".fastq.gz -> parallel inflate -> predict -> chop (src/bin/predict.rs:130-192) -> BGZF, no .pt in between",
+                           ".fastq.gz -> parallel inflate -> predict -> chop (src/bin/predict.rs:130-192) -> BGZF, no .pt in between" +
+                           ("" if reference_batch is None else f"; the reads in the reference's left-padded batches of {reference_batch} "
+                            "(--reference-batching: the predictions of the reference's default `predict -b 12`), [PAD] runs shared per launch"),
+               "batching": "every read at its own length" if reference_batch is None else f"reference batches of {reference_batch}",
                "value": round(n_in / dt, 1), "unit": "reads/s", "Mbases_per_s": round(n_bases / dt / 1e6, 2), "reads": n_in,
                "mean_bp": round(n_bases / n_reads, 1), "seconds": round(dt, 3), "bgzf_threads": threads,
                "input_MB": round(os.path.getsize(path) / 1e6, 1), "output_MB": round(os.path.getsize(final) / 1e6, 1),
@@ -223,7 +228,7 @@ def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24) -> dict:
         check = {"records_match_driver_report": counts["records"] == n_out, "reads_in_match": n_in == n_reads,
                  "bases_out_le_bases_in": counts["bases_out"] <= n_bases}
         if check_reads:
-            check.update(_chop_head_check(sd, head, final))
+            check.update(_chop_head_check(sd, head, final, reference_batch or 1))
         out["check"] = check
     finally:
         os.chdir(cwd)
@@ -231,21 +236,28 @@ def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24) -> dict:
     return out
 
 
-def _chop_head_check(sd, head, final_path: str) -> dict:
-    """The first reads through the oracle: tokenise -> forward (torch fp32) -> argmax -> chop_read, compared with the head
-    of the chopped file byte for byte."""
+def _chop_head_check(sd, head, final_path: str, batch: int = 1) -> dict:
+    """The first reads through the oracle: tokenise -> collate in batches of `batch` (left-padded, as the reference's
+    DataLoader forms them) -> forward (torch fp32) -> argmax -> chop_read, compared with the head of the chopped file
+    byte for byte."""
     from oracle import dc_oracle as o
     from oracle import forward_ref as fr
 
     headers, seqs, quals = head
     want = []
+    feats = []
     for h, s, q in zip(headers, seqs, quals):
         name = h.split(b" ", 1)[0]
         rec = o.parse_fastq_record(name.decode(), s.decode(), q.decode())
-        f = o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"])
-        b = o.collate([f])
+        feats.append(o.tokenize_and_align_labels_and_quals_ids(rec["id"], rec["seq"], rec["qual"], rec["target"]))
+    preds = {}
+    for b0 in range(0, len(feats), batch):
+        b = o.collate(feats[b0: b0 + batch])
         logits = fr.forward(sd, b["input_ids"], b["input_quals"]).numpy()
-        p = o.load_predicts_from_batch({"prediction": logits, "target": b["labels"], "seq": b["input_ids"], "id": b["id"]})[name.decode()]
+        preds.update(o.load_predicts_from_batch({"prediction": logits, "target": b["labels"], "seq": b["input_ids"], "id": b["id"]}))
+    for h, s, q in zip(headers, seqs, quals):
+        name = h.split(b" ", 1)[0]
+        p = preds[name.decode()]
         for rid, rs, rq in o.chop_read(p, name, s, q, fq_header=h):  # the chop binary's defaults (src/bin/predict.rs:39-64)
             want.append(b"@" + rid + b"\n" + rs + b"\n+\n" + rq + b"\n")
     want = b"".join(want)
@@ -353,7 +365,7 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
             n = 0
             first = None
             with FastqReader(path) as rd:
-                for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 1_000_000), reference_padding=True, ids_i64=True):
+                for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 2_000_000, padded=not pipe.shared_prefix), reference_padding=True, ids_i64=True):
                     if first is None:
                         k, c0 = res["sub_sizes"][0], res["sub_cols"][0]
                         o = res["offsets"]
@@ -371,6 +383,20 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
         n, first = run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        stage_ms = None
+        if os.environ.get("DC_LEG_STAGES"):  # a second, untimed pass with the kernels bracketed by events: where the GPU time goes
+            net = pipe.model.net
+            net.set_profiling(True)
+            net.profile_reset()
+            try:
+                run()
+                torch.cuda.synchronize()
+                prof = net.profile()
+            finally:
+                net.set_profiling(False)
+            fw = prof.get("forward", (0.0, 0))[0]
+            stage_ms = {k: {"ms": round(v[0], 1), "launches": int(v[1]), "share_of_forward": round(v[0] / fw, 4) if fw else None}
+                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {"workload": "the reference's default batching: FASTQ file -> batches of 12 (left-padded per batch, pad tokens through the "
@@ -381,6 +407,8 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
            "mean_bp": round(bases / n_reads, 1), "max_bp": int(lens.max()),
            "padded_over_real_tokens": round(padded / float(bases + n_reads), 3),
            "shared_pad_prefix": bool(getattr(pipe, "shared_prefix", False))}
+    if stage_ms is not None:
+        out["stages"] = stage_ms
     from oracle import dc_oracle as o
     from oracle import forward_ref as fr
 
