@@ -86,6 +86,7 @@ _SIGNATURES = {
     "dc_forward_ragged": (C.c_int, [vp, vp, vp, i32, vp, i32, i64, C.POINTER(i32), C.POINTER(i32), vp]),
     "dc_forward_shared_prefix": (C.c_int, [vp, vp, vp, i32, vp, i32, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, vp]),
     "dc_model_prefix_violations": (C.c_int, [vp, vp, C.POINTER(i32)]),
+    "dc_model_set_prefix_mode": (C.c_int, [vp, i32]),
     "dc_head_forward": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "dc_model_device_bytes": (i64, [vp]),
     "dc_model_filter": (C.c_int, [vp, vp, i32, i32, vp]),

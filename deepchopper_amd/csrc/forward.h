@@ -100,6 +100,14 @@ struct HyenaArgs {
   // (toff[r] = first own slot - pv[r]).  Only own positions are stored.
   const int32_t* pv;              // [n_reads] positions in front of the read's own slots
   const int32_t* padoff;          // [n_reads] slot of the shared row that stands for the read's position 0
+  // Linear form of the shared prefix (dbase != nullptr): the convolution is linear, so with z_pad / F = k * z_pad of the ONE
+  // shared row known, a read's output is  y[t] = ((k * (z - z_pad))[t] + F[t]) * gate[t]  and z - z_pad vanishes over the whole
+  // pad run: the read's sequence starts 4 positions in front of its own slots (pv = 4: the short filter's halo) instead of
+  // at the head of its pad run -- the long convolution costs what it costs without padding.
+  const int32_t* dbase;           // [n_reads] index of the read's position 0 in the rows of zc / Fc (a multiple of 4)
+  const float* zc;                // [D][dstride] gated input z of the shared row (0 in front of it: reads without a pad run)
+  const float* Fc;                // [D][dstride] its long convolution k * z_pad, before the output gate
+  int64_t dstride;
 };
 
 int launch_gemm(hipStream_t st, const GemmArgs& g, int epi, bool ln);
@@ -136,6 +144,10 @@ int launch_load_hidden(hipStream_t st, const float* hidden, const float* quals, 
                        const int32_t* toff, const int64_t* src_base, const int32_t* ntok, int64_t Tp, float* x,
                        float* qpad);
 int launch_ln_stats(hipStream_t st, const float* x, int D, int64_t Tp, float eps, float* mean, float* rstd);
+// linear form of the shared [PAD] prefix: y slots of the shared row hold F = k * z_pad (unit-gate pass) -> zc / Fc rows at z0 + t, y = F * gate
+// (tab != nullptr: layer 0, u is the table row of pad_id)
+int launch_pad_row_finish(hipStream_t st, const float* u, const float* tab, int pad_id, int D, int64_t Tp, int pad_toff, int L,
+                          const float* sw, const float* sb, float* y, float* zc, float* Fc, int64_t dstride, int z0);
 int launch_head_reduce(hipStream_t st, const float* part, int n_part, const float* b3, int64_t Tp,
                        const int32_t* blk_read, const int32_t* toff, const int64_t* src_base, const int32_t* ntok,
                        float* logits, float* padlog);  // src_base[r] < 0: logits of a shared [PAD] row -> padlog + (-1 - src_base[r])

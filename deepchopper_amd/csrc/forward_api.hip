@@ -20,6 +20,7 @@ struct DevBuf {
 struct LayerDev {
   float *Wt_in = nullptr, *b_in = nullptr;    // [D][3D], [3D]   (norm1 folded)
   float *sw = nullptr, *sb = nullptr;         // [3D][3], [3D]
+  float *sw_unit = nullptr, *sb_unit = nullptr;  // the same with x0's taps zeroed and its bias 1: a unit output gate (linear shared prefix)
   float *Wt_out = nullptr, *b_out = nullptr;  // [D][D], [D]
   float *Wt_fc1 = nullptr, *b_fc1 = nullptr;  // [D][DI], [DI]  (norm2 folded)
   float *Wt_fc2 = nullptr, *b_fc2 = nullptr;  // [DI][D], [D]
@@ -38,6 +39,10 @@ struct LayerDev {
   float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
   float* kspec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 10..15
 };
+
+// linear shared prefix: positions of the zero stretch in front of the shared row's in the zc / Fc rows (>= the longest sequence
+// of a read without a pad run + the 32-token block its kernels may read past its end)
+constexpr int kPrefixZero = 32768 + 128;
 
 struct ProfEvent {
   hipEvent_t a, b;
@@ -97,6 +102,12 @@ struct dc_model {
   int64_t* d_fill_dst = nullptr;    // [n_reads] dense position of a row's first pad column
   int32_t *d_fill_n = nullptr, *d_fill_src = nullptr;  // [n_reads] pad columns of the row; position 0 of its shared row in padlog
   bool shared_prefix = false;       // the cached geometry has shared [PAD] rows
+  int prefix_mode = 1;              // dc_forward_shared_prefix: 1 = exact form (a row per long-convolution class, reads walk their pad runs), 2 = linear form
+  bool linear_prefix = false;       // ... and they are the linear form's ONE row
+  int32_t* d_dbase = nullptr;       // [n_units] linear form: index of a read's position 0 in the zc / Fc rows
+  DevBuf zc, Fc;                    // linear form: [D][dcap] gated input / long convolution of the shared row behind a zero stretch
+  int64_t dcap = 0;                 // their row stride
+  int lin_pad_cls = -1, lin_pad_len = 0, lin_pad_P = 0, lin_pad_toff = 0, lin_pad_fft_index = 0;  // the shared row: class, tokens, blocks, slot, entry in d_fft_reads
   int n_fill_rows = 0, pad_id = 0;
   DevBuf padlog;                    // float2 per position of the shared [PAD] rows: their logits
   int* d_prefix_bad = nullptr;      // tokens inside a declared pad prefix that were not ([PAD], quality 0)
@@ -465,7 +476,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   key.push_back((int32_t)(row_stride & 0x7fffffff));
   key.push_back((int32_t)(row_stride >> 31));
   key.push_back(m->fft_min_tokens);
-  key.push_back(h_npad ? 1 + pad_id : 0);
+  key.push_back(h_npad ? 1 + pad_id + 1024 * m->prefix_mode : 0);
   key.insert(key.end(), h_first, h_first + n_reads);
   key.insert(key.end(), h_ntok, h_ntok + n_reads);
   if (h_npad) key.insert(key.end(), h_npad, h_npad + n_reads);
@@ -483,13 +494,20 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     return 0;
   };
 
-  // Shared [PAD] rows: one per long-convolution class that holds reads with a pad run, as long as the longest run (rounded
-  // down to a multiple of 4: a read owns the last <= 3 pads in front of its first base, so that the 16-byte accesses of the
-  // long-convolution kernels never straddle the two sources).  A row per CLASS because a read's pad positions must see what
-  // they would have seen inside the read's own sequence: the block-Toeplitz forms are exactly causal and bit-identical to
-  // one another, so one row serves them all bit for bit; an FFT form's result depends (in the last bits) on the transform.
+  // Shared [PAD] rows.
+  // Exact form (prefix_mode 1): one row per long-convolution class that holds reads with a pad run, as long as the longest run
+  // (rounded down to a multiple of 4: a read owns the last <= 3 pads in front of its first base, so that the 16-byte accesses
+  // of the long-convolution kernels never straddle the two sources).  A row per CLASS because a read's pad positions must see
+  // what they would have seen inside the read's own sequence: the block-Toeplitz forms are exactly causal and bit-identical
+  // to one another, so one row serves them all bit for bit; an FFT form's result depends (in the last bits) on the transform.
+  // The long convolution of a read still walks its whole padded sequence.
+  // Linear form (prefix_mode 2): ONE row as long as the longest padded row.  The convolution is linear: with z_pad and
+  // F = k * z_pad of that row known, y = (k * (z - z_pad) + F) * gate, and z - z_pad is zero over a read's whole pad run -- a
+  // read's sequence starts 4 positions in front of its own slots (the short filter's halo) and its long convolution
+  // costs what it costs without padding; its class follows its own length.
+  const bool linear = h_npad && m->prefix_mode == 2;
   int pad_len[7] = {0, 0, 0, 0, 0, 0, 0};
-  std::vector<int32_t> pv(n_reads, 0);
+  std::vector<int32_t> pv(n_reads, 0), t0(n_reads, 0);  // pv: positions of a read's sequence the shared row holds; t0: position of the shared row the read's sequence starts at
   int n_fill = 0;
   for (int r = 0; r < n_reads; ++r) {
     DC_REQUIRE(h_ntok[r] >= 1, "every read needs at least one token");
@@ -498,8 +516,15 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     DC_REQUIRE(h_npad[r] >= 0 && h_npad[r] < h_ntok[r], "a read's pad run must be shorter than the read");
     pv[r] = h_npad[r] & ~3;
     n_fill += pv[r] > 0;
-    const int k = conv_class(h_ntok[r]);
-    pad_len[k] = std::max(pad_len[k], (int)pv[r]);
+    if (linear) {
+      if (pv[r] > 0) {
+        t0[r] = pv[r] - 4;
+        pad_len[0] = std::max(pad_len[0], (int)h_ntok[r]);  // F is needed wherever a read that leans on the row has positions
+      }
+    } else {
+      const int k = conv_class(h_ntok[r]);
+      pad_len[k] = std::max(pad_len[k], (int)pv[r]);
+    }
   }
   int pad_unit[7], n_units = n_reads;
   int64_t padlog_len = 0;
@@ -513,6 +538,9 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     }
   }
   const bool sp = n_units > n_reads;
+  // linear form: zc / Fc rows = [a zero stretch every read without a pad run points at | the shared row's positions | slack]
+  constexpr int kZero = kPrefixZero;
+  const int64_t dstride = linear && sp ? (int64_t)kZero + ((pad_len[0] + 3) & ~3) + 64 : 0;
 
   // Packed layout: a unit starts at a multiple of 4 token slots (16-byte aligned fp32 rows for the float4 / 8-byte
   // accesses of the long-convolution kernels) and owns ceil4(own tokens) slots.  (Rounds 1-2 gave every read whole 32-token
@@ -520,24 +548,26 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   // kernels still walk a read in 32-token blocks: the tail of its last block overlaps the next read's slots, which they
   // may READ (causal: a later position never reaches an earlier output) but must not write -- their stores are masked
   // by the read's slot count.  32 slots of slack behind the last read keep those reads inside the buffers.
-  std::vector<int32_t> nblk(n_units), toff(n_units), nown(n_units), ctoff(n_units), cntok(n_units), upv(n_units, 0), padoff(n_units, 0);
+  std::vector<int32_t> nblk(n_units), toff(n_units), nown(n_units), ctoff(n_units), cntok(n_units), upv(n_units, 0), padoff(n_units, 0),
+      dbase(n_units, 0);
   std::vector<int32_t> ucls(n_units);
   std::vector<int64_t> src_base(n_units);
   int64_t slots = 0;
   int maxP = 0, minP = 1 << 30;
   for (int u = 0; u < n_units; ++u) {
     if (u < n_reads) {
-      upv[u] = pv[u];
-      cntok[u] = h_ntok[u];
+      upv[u] = pv[u] - t0[u];           // exact form: the pad run (floor 4); linear form: 4 (or 0: a read that owns all of its positions)
+      cntok[u] = h_ntok[u] - t0[u];
       nown[u] = h_ntok[u] - pv[u];
       src_base[u] = (int64_t)u * row_stride + h_first[u] + pv[u];
-      ucls[u] = conv_class(h_ntok[u]);
+      ucls[u] = conv_class(cntok[u]);
+      if (linear && pv[u] > 0) dbase[u] = kZero + t0[u];
     } else {
       int k = 0;
       while (pad_unit[k] != u) ++k;
       cntok[u] = nown[u] = pad_len[k];
       src_base[u] = -1 - (int64_t)padlog_off[k];
-      ucls[u] = k;
+      ucls[u] = linear ? conv_class(pad_len[k]) : k;
     }
     nblk[u] = (cntok[u] + 31) / 32;
     DC_REQUIRE(slots < ((int64_t)1 << 31) - 64, "batch too large for 32-bit token offsets");
@@ -548,7 +578,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     minP = std::min(minP, nblk[u]);
   }
   for (int r = 0; r < n_reads; ++r)
-    if (pv[r] > 0) padoff[r] = toff[pad_unit[ucls[r]]];
+    if (pv[r] > 0) padoff[r] = toff[pad_unit[linear ? 0 : ucls[r]]] + t0[r];
   const int64_t Tp = ((slots + 32 + 255) / 256) * 256;  // + slack, then a multiple of every GEMM token tile
   DC_REQUIRE(Tp < ((int64_t)1 << 31), "batch too large (token count must fit int32)");
   DC_REQUIRE((int64_t)maxP * 32 <= m->cfg.max_seq_len + 31, "read longer than the model's max_seq_len");
@@ -559,15 +589,19 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   std::vector<int32_t> order(n_units);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nblk[a] > nblk[b]; });
+  // (linear form: the shared row runs in a launch of its own in front of the reads' -- they need its z and F -- as a group / a
+  //  read list of one behind the others')
+  const int lin_pad = linear && sp ? pad_unit[0] : -1;
   std::vector<int32_t> fft_lists[6], mfma_order;
   for (int j = 0; j < n_units; ++j) {
     const int u = order[j];
+    if (u == lin_pad) continue;
     if (ucls[u] > 0) fft_lists[ucls[u] - 1].push_back(u);
     else mfma_order.push_back(u);
   }
   const int n_mfma = (int)mfma_order.size();
   const int n_groups = (n_mfma + 31) / 32;
-  std::vector<int32_t> grp_reads((size_t)std::max(n_groups, 1) * 32, -1), grp_P(std::max(n_groups, 1), 0);
+  std::vector<int32_t> grp_reads((size_t)(n_groups + 1) * 32, -1), grp_P(n_groups + 1, 0);
   int maxP_mfma = 0;
   for (int j = 0; j < n_mfma; ++j) {
     grp_reads[j] = mfma_order[j];
@@ -579,6 +613,19 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     m->fft_offset[b] = (int)fft_reads.size();
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
+  }
+  m->lin_pad_cls = -1;
+  if (lin_pad >= 0) {
+    m->lin_pad_cls = ucls[lin_pad];
+    m->lin_pad_len = pad_len[0];
+    m->lin_pad_P = nblk[lin_pad];
+    m->lin_pad_toff = toff[lin_pad];
+    if (ucls[lin_pad] == 0) {
+      grp_reads[(size_t)n_groups * 32] = lin_pad;
+      grp_P[n_groups] = nblk[lin_pad];
+    }
+    m->lin_pad_fft_index = (int)fft_reads.size();
+    fft_reads.push_back(lin_pad);
   }
   std::vector<int32_t> blk_read(n_tb, -1);  // unit that owns slots [4 i, 4 i + 4), -1 = none
   for (int u = 0; u < n_units; ++u) {
@@ -594,7 +641,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
       if (pv[r] > 0) {  // (the last <= 3 pads of a run are the read's own: their logits come from its own slots)
         fill_dst[j] = (int64_t)r * row_stride + h_first[r];
         fill_n[j] = pv[r];
-        fill_src[j] = padlog_off[ucls[r]];
+        fill_src[j] = linear ? 0 : padlog_off[ucls[r]];
         ++j;
       }
   }
@@ -612,7 +659,8 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   size_t o_cntok = al8(o_ctoff + i4 * nu);
   size_t o_pv = al8(o_cntok + i4 * nu);
   size_t o_pad = al8(o_pv + i4 * nu);
-  size_t o_fn = al8(o_pad + i4 * nu);
+  size_t o_db = al8(o_pad + i4 * nu);
+  size_t o_fn = al8(o_db + i4 * nu);
   size_t o_fs = al8(o_fn + i4 * fill_n.size());
   size_t o_gr = al8(o_fs + i4 * fill_src.size());
   size_t o_gp = al8(o_gr + i4 * grp_reads.size());
@@ -650,6 +698,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   memcpy(hp + o_cntok, cntok.data(), i4 * nu);
   memcpy(hp + o_pv, upv.data(), i4 * nu);
   memcpy(hp + o_pad, padoff.data(), i4 * nu);
+  memcpy(hp + o_db, dbase.data(), i4 * nu);
   memcpy(hp + o_fn, fill_n.data(), i4 * fill_n.size());
   memcpy(hp + o_fs, fill_src.data(), i4 * fill_src.size());
   memcpy(hp + o_gr, grp_reads.data(), i4 * grp_reads.size());
@@ -670,12 +719,24 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   m->d_cntok = (int32_t*)(dp + o_cntok);
   m->d_pv = (int32_t*)(dp + o_pv);
   m->d_padoff = (int32_t*)(dp + o_pad);
+  m->d_dbase = (int32_t*)(dp + o_db);
   m->d_fill_n = (int32_t*)(dp + o_fn);
   m->d_fill_src = (int32_t*)(dp + o_fs);
   m->d_grp_reads = (int32_t*)(dp + o_gr);
   m->d_grp_P = (int32_t*)(dp + o_gp);
   m->d_fft_reads = (int32_t*)(dp + o_fr);
   m->shared_prefix = sp;
+  m->linear_prefix = linear && sp;
+  if (dstride > m->dcap) {
+    // The rows keep the stride they were allocated with (a new stride would move the zero stretches onto old data): grow in
+    // steps, zero-filled -- the stretch in front of the shared row's positions is what reads without a pad run subtract / add
+    const int64_t cap = ((dstride + 8191) / 8192) * 8192;
+    const size_t need = (size_t)m->cfg.d_model * cap * sizeof(float);
+    DC_HIP_CHECK(hipStreamSynchronize(st));
+    int rc;
+    if ((rc = ensure(m->zc, need)) || (rc = ensure(m->Fc, need))) return rc;
+    m->dcap = cap;
+  }
   m->n_fill_rows = n_fill;
   m->pad_id = pad_id;
   m->max_P_mfma = maxP_mfma;
@@ -744,17 +805,18 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   // taps: the longest read, and every tap an FFT size class in use transforms (its spectrum is built from min(taps, M)
   // taps: materialising all M makes it -- and with it the last bits of the result -- independent of what the handle saw before)
   int64_t taps_needed = (int64_t)m->max_P * 32;
+  const int pad_fft = m->linear_prefix && m->lin_pad_cls > 0 ? m->lin_pad_cls - 1 : -1;  // the linear form's shared row on an FFT class
   for (int b = 0; b < 6; ++b)
-    if (m->fft_count[b]) taps_needed = std::max<int64_t>(taps_needed, (int64_t)1 << (10 + b));
+    if (m->fft_count[b] || b == pad_fft) taps_needed = std::max<int64_t>(taps_needed, (int64_t)1 << (10 + b));
   if ((rc = ensure_filters(m, st, taps_needed))) return rc;
   for (int b = 0; b < 6; ++b)
-    if (m->fft_count[b] && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
+    if ((m->fft_count[b] || b == pad_fft) && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
   // reads per launch pair of the 2^15 form.  The scratch is D x 2^15 complex = 64 MiB per read and stays with the handle, so
   // the batch is what bounds a handle's footprint: 4 reads = 256 MiB at most (16 would hold 1 GiB for good, per handle --
   // lanes, or ranks sharing a GPU), and a launch of 4 reads is already 8 x 4 x 256 = 8 192 workgroups
   constexpr int kFft15Batch = 4;
-  if (m->fft_count[5]) {
-    const size_t need = (size_t)hyena_fft15_scratch_bytes(std::min(m->fft_count[5], kFft15Batch), c.d_model);
+  if (m->fft_count[5] || pad_fft == 5) {
+    const size_t need = (size_t)hyena_fft15_scratch_bytes(std::max(1, std::min(m->fft_count[5], kFft15Batch)), c.d_model);
     if (m->fft_scratch.bytes < need) {
       DC_HIP_CHECK(hipStreamSynchronize(st));  // earlier launches may still read the buffer about to be freed
       // every (k1, b) of a (read, channel) is stored by the first kernel before the second one loads it: no zero fill
@@ -848,6 +910,33 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       // long-convolution kernel: 3 = 16-bit split MFMA (with the split GEMM modes), 2 = fp32 MFMA
       const int hy_env = getenv("DC_HYENA") ? atoi(getenv("DC_HYENA")) : 0;
       const int hy = hy_env ? hy_env : (m->gemm_mode >= 1 ? 3 : 2);
+      if (m->linear_prefix) {
+        // the shared [PAD] row first, alone, with a unit output gate: F = k * z_pad into its y slots; then z_pad, F -> zc / Fc
+        // and y = F * gate (launch_pad_row_finish).  The reads' launches below subtract z_pad and add F.
+        ProfScope pp(m, st, "hyena_pad_row");
+        HyenaArgs ap = a;
+        ap.pv = ap.padoff = ap.dbase = nullptr;
+        ap.sw = L.sw_unit;
+        ap.sb = L.sb_unit;
+        const int k = m->lin_pad_cls;
+        if (k == 0) {
+          ap.grp_reads = a.grp_reads + (size_t)m->n_groups * 32;
+          ap.grp_P = a.grp_P + m->n_groups;
+          rc = hy == 2 ? launch_hyena2(st, ap, 1, m->lin_pad_P) : launch_hyena3(st, ap, 1, m->lin_pad_P);
+        } else if (k <= 5) {
+          rc = launch_hyena_fft(st, ap, 10 + k - 1, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[k - 1]);
+        } else {
+          rc = launch_hyena_fft15(st, ap, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[5], (float*)m->fft_scratch.p);
+        }
+        if (rc) return rc;
+        if ((rc = launch_pad_row_finish(st, u, a.tok ? a.tab : nullptr, m->pad_id, D, Tp, m->lin_pad_toff, m->lin_pad_len, L.sw, L.sb, y,
+                                        (float*)m->zc.p, (float*)m->Fc.p, m->dcap, kPrefixZero)))
+          return rc;
+        a.dbase = m->d_dbase;
+        a.zc = (const float*)m->zc.p;
+        a.Fc = (const float*)m->Fc.p;
+        a.dstride = m->dcap;
+      }
       if (m->n_groups > 0) {
         const bool one_launch = getenv("DC_H3_ONE_LAUNCH") != nullptr;  // A/B
         if (hy == 3 && !one_launch && m->n_groups_long > 0 && m->n_groups_long < m->n_groups) {
@@ -982,6 +1071,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   if (const char* e = getenv("DC_GEMM_MODE"))
     m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : ((strcmp(e, "fp16x3") == 0 || strcmp(e, "2") == 0) ? 2 : 1);
   if (const char* e = getenv("DC_FFT_MIN")) m->fft_min_tokens = std::max(256, atoi(e));
+  if (const char* e = getenv("DC_PREFIX_MODE")) m->prefix_mode = (strcmp(e, "linear") == 0 || strcmp(e, "2") == 0) ? 2 : 1;
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
   {
@@ -1042,6 +1132,13 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
     UP(upload(m, bo, &L.b_in));
     UP(upload_raw(m, lw.short_w, (size_t)3 * D * 3, &L.sw));
     UP(upload_raw(m, lw.short_b, (size_t)3 * D, &L.sb));
+    {
+      std::vector<float> swu(lw.short_w, lw.short_w + (size_t)3 * D * 3), sbu(lw.short_b, lw.short_b + (size_t)3 * D);
+      std::fill(swu.begin(), swu.begin() + (size_t)D * 3, 0.f);
+      std::fill(sbu.begin(), sbu.begin() + D, 1.f);
+      UP(upload(m, swu, &L.sw_unit));
+      UP(upload(m, sbu, &L.sb_unit));
+    }
     fold_transpose(lw.out_proj_w, lw.out_proj_b, nullptr, nullptr, D, D, Wt, bo);
     UP(upload(m, Wt, &L.Wt_out));
     UP(upload_planes(m, Wt, D, D, &L.Wp_out));
@@ -1118,7 +1215,7 @@ extern "C" void dc_model_free(dc_model* m) {
   }
   if (m->fft_tw) (void)hipFree(m->fft_tw);
   for (DevBuf* b : {&m->x, &m->u, &m->y, &m->hmid, &m->obuf, &m->mean, &m->rstd, &m->qpad, &m->idx, &m->part, &m->tok, &m->padlog,
-                    &m->fft_scratch})
+                    &m->fft_scratch, &m->zc, &m->Fc})
     if (b->p) (void)hipFree(b->p);
   if (m->pinned) (void)hipHostFree(m->pinned);
   if (m->staging_done) (void)hipEventDestroy(m->staging_done);
@@ -1157,6 +1254,13 @@ extern "C" int dc_forward_shared_prefix(dc_model* m, void* stream, const void* d
   DC_REQUIRE(pad_token_id >= 0 && pad_token_id < m->cfg.vocab, "pad_token_id outside the vocabulary");
   return forward_core(m, as_stream(stream), d_input_ids, ids_i64, d_input_quals, n_reads, row_stride, h_first,
                       h_n_tokens, d_logits, h_n_pad, pad_token_id);
+}
+
+extern "C" int dc_model_set_prefix_mode(dc_model* m, int32_t mode) {
+  DC_REQUIRE(m, "null pointer");
+  DC_REQUIRE(mode == 1 || mode == 2, "prefix mode must be 1 (exact form) or 2 (linear form)");
+  m->prefix_mode = mode;
+  return DC_OK;
 }
 
 extern "C" int dc_model_prefix_violations(dc_model* m, void* stream, int32_t* count) {

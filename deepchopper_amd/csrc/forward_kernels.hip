@@ -1547,8 +1547,9 @@ constexpr int HY_ZSTRIDE = 36;  // floats per read row of the z tile: 16-B align
 #endif
 constexpr int HY_NW = DC_HY_NW, HY_ACC = 32 / HY_NW;
 
-template <bool SP>  // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
+template <int SP>  // SP: 1 = reads with a shared [PAD] prefix (HyenaArgs::pv / padoff), 2 = its linear form (+ dbase / zc / Fc)
 __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_kernel(HyenaArgs a) {
+  constexpr bool DL = SP == 2;  // y = (k * (z - z_pad) + F) * gate: the convolution runs over the read's own positions only
   extern __shared__ float s_mem[];
   const int g = blockIdx.x;
   const int c = blockIdx.y;
@@ -1581,6 +1582,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   const int z_pv = SP ? a.pv[rz] : 0;             // positions in front of it come from the shared [PAD] row
   const int64_t z_pad = SP ? a.padoff[rz] : 0;
   auto zslot = [&](int64_t t) -> int64_t { return (SP && t < z_pv ? z_pad : z_off) + t; };  // slot of the quad at position t
+  const float* zcrow = DL ? a.zc + (int64_t)c * a.dstride + a.dbase[rz] : nullptr;  // DL: the shared row's z at the read's positions
   const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp;
   const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp;
   const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
@@ -1588,6 +1590,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   const float wv_0 = a.sw[(2 * a.D + c) * 3 + 0], wv_1 = a.sw[(2 * a.D + c) * 3 + 1],
               wv_2 = a.sw[(2 * a.D + c) * 3 + 2], bv = a.sb[2 * a.D + c];
 
+  float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);  // DL: z_pad of the quad z_load fetched last
   auto z_load = [&](int p, float4& l1, float4& c1, float4& lv, float4& cv) {
     l1 = c1 = lv = cv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (producer && p < z_nblk) {
@@ -1600,16 +1603,18 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
       const int64_t sc = zslot(t);
       c1 = *reinterpret_cast<const float4*>(ux1 + sc);
       cv = *reinterpret_cast<const float4*>(uv + sc);
+      if (DL) zs = *reinterpret_cast<const float4*>(zcrow + t);
     }
   };
   auto z_store = [&](int p, const float4& l1, const float4& c1, const float4& lv, const float4& cv) {
     // conv1d(padding=2)[..., :L]: out[t] = w0 u[t-2] + w1 u[t-1] + w2 u[t] + b ;  z = sf(v) * sf(x1)
     float4 z;
-    const bool act = p < z_nblk;
+    const bool act = p < z_nblk && (!DL || 32 * p + zq4 >= z_pv);  // (DL: z - z_pad is zero over the shared row's positions)
     z.x = fmaf(wx1_0, l1.z, fmaf(wx1_1, l1.w, fmaf(wx1_2, c1.x, bx1))) * fmaf(wv_0, lv.z, fmaf(wv_1, lv.w, fmaf(wv_2, cv.x, bv)));
     z.y = fmaf(wx1_0, l1.w, fmaf(wx1_1, c1.x, fmaf(wx1_2, c1.y, bx1))) * fmaf(wv_0, lv.w, fmaf(wv_1, cv.x, fmaf(wv_2, cv.y, bv)));
     z.z = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
     z.w = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
+    if (DL) z = make_float4(z.x - zs.x, z.y - zs.y, z.z - zs.z, z.w - zs.w);
     if (!act) z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (producer) *reinterpret_cast<float4*>(s_z + (p & 1) * (32 * HY_ZSTRIDE) + zr * HY_ZSTRIDE + zq4) = z;
   };
@@ -1671,6 +1676,7 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
   const int64_t my_pad = SP ? a.padoff[r] : 0;
   auto xslot = [&](int64_t t) -> int64_t { return (SP && t < my_pv ? my_pad : off) + t; };
   const float* ux0 = a.u + (int64_t)c * a.Tp;
+  const float* fcrow = DL ? a.Fc + (int64_t)c * a.dstride + a.dbase[r] : nullptr;  // DL: the shared row's convolution at the read's positions
   float* yrow = a.y + (int64_t)c * a.Tp + off;
   const float wx0_0 = a.sw[c * 3 + 0], wx0_1 = a.sw[c * 3 + 1], wx0_2 = a.sw[c * 3 + 2], bx0 = a.sb[c];
 #pragma unroll
@@ -1687,11 +1693,13 @@ __global__ __launch_bounds__(64 * DC_HY_NW, DC_HY_NW == 4 ? 2 : 4) void hyena2_k
         const float g1 = fmaf(wx0_0, lo.w, fmaf(wx0_1, cu.x, fmaf(wx0_2, cu.y, bx0)));
         const float g2 = fmaf(wx0_0, cu.x, fmaf(wx0_1, cu.y, fmaf(wx0_2, cu.z, bx0)));
         const float g3 = fmaf(wx0_0, cu.y, fmaf(wx0_1, cu.z, fmaf(wx0_2, cu.w, bx0)));
+        float4 fq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DL) fq = *reinterpret_cast<const float4*>(fcrow + t);
         float4 o;
-        o.x = acc[m][4 * gq + 0] * g0;
-        o.y = acc[m][4 * gq + 1] * g1;
-        o.z = acc[m][4 * gq + 2] * g2;
-        o.w = acc[m][4 * gq + 3] * g3;
+        o.x = (acc[m][4 * gq + 0] + fq.x) * g0;
+        o.y = (acc[m][4 * gq + 1] + fq.y) * g1;
+        o.z = (acc[m][4 * gq + 2] + fq.z) * g2;
+        o.w = (acc[m][4 * gq + 3] + fq.w) * g3;
         if (t < my_nt4 && t >= my_pv) *reinterpret_cast<float4*>(yrow + t) = o;
       }
     }
@@ -1703,12 +1711,15 @@ int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   // LDS of the largest chunk: filter taps [32 + 32 * 32 * n_oc] + two z tiles
   const size_t lds = ((size_t)32 + 32 * 32 * (size_t)n_oc + 2 * 32 * HY_ZSTRIDE) * sizeof(float);
   DC_REQUIRE(lds <= 160 * 1024, "read too long for the LDS-resident filter");
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<false>, 160 * 1024);  // the permitted maximum; a launch asks for `lds`
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<true>, 160 * 1024);
-  if (a.pv)
-    hipLaunchKernelGGL(hyena2_kernel<true>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<0>, 160 * 1024);  // the permitted maximum; a launch asks for `lds`
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<1>, 160 * 1024);
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE(hyena2_kernel<2>, 160 * 1024);
+  if (a.pv && a.dbase)
+    hipLaunchKernelGGL(hyena2_kernel<2>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
+  else if (a.pv)
+    hipLaunchKernelGGL(hyena2_kernel<1>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
   else
-    hipLaunchKernelGGL(hyena2_kernel<false>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
+    hipLaunchKernelGGL(hyena2_kernel<0>, dim3(n_groups, a.D, n_oc), dim3(64 * HY_NW), lds, st, a);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
@@ -1818,9 +1829,9 @@ int launch_filter_planes(hipStream_t st, const float* kf, int D, int kf_taps, un
   return DC_OK;
 }
 
-template <int CB, int MODE, bool TAB, bool SP>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16;
-                                                // TAB: u gathered from the layer-0 table by token id (HyenaArgs::tok / tab);
-                                                // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
+template <int CB, int MODE, bool TAB, int SP>  // CB: blocks per output chunk, 32 (reads <= 1024 tokens, one filter window) or 16;
+                                               // TAB: u gathered from the layer-0 table by token id (HyenaArgs::tok / tab);
+                                               // SP: 1 = reads with a shared [PAD] prefix (HyenaArgs::pv / padoff), 2 = its linear form
 #ifndef DC_H3_OCC
 #define DC_H3_OCC 2
 #endif
@@ -1831,6 +1842,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   typedef SplitMode<MODE> SM;
   typedef typename SM::vec svec;
   constexpr int NP = SM::NP;
+  constexpr bool DL = SP == 2;  // y = (k * (z - z_pad) + F) * gate: the convolution runs over the read's own positions only
   constexpr int H3_FILT_BYTES = h3_filt_bytes(NP), H3_ZBUF_BYTES = h3_zbuf_bytes(NP);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_h3[];
   __shared__ float s_tab3[3 * 17];  // TAB: x0 | x1 | v of this channel for token ids 0..15, entry 16 = 0 (no token)
@@ -1859,6 +1871,8 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   const int z_pv = SP ? a.pv[rz] : 0;          // positions in front of it come from the shared [PAD] row
   const int z_pad = SP ? a.padoff[rz] : 0;
   auto zslot = [&](int t) -> int { return (SP && t < z_pv ? z_pad : z_off) + t; };  // slot of the quad at position t
+  const float* zcrow = DL ? a.zc + (int64_t)c * a.dstride + a.dbase[rz] : nullptr;  // DL: the shared row's z at the read's positions
+  float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);                                        // ... of the quad fetched last
   const float* ux1 = a.u + (int64_t)(a.D + c) * a.Tp;
   const float* uv = a.u + (int64_t)(2 * a.D + c) * a.Tp;
   const float wx1_0 = a.sw[(a.D + c) * 3 + 0], wx1_1 = a.sw[(a.D + c) * 3 + 1], wx1_2 = a.sw[(a.D + c) * 3 + 2],
@@ -1885,6 +1899,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
         const int t = 32 * p + zq4;
         if (t > 0) il = *reinterpret_cast<const uint32_t*>(tkz + zslot(t - 4));
         ic = *reinterpret_cast<const uint32_t*>(tkz + zslot(t));
+        if (DL) zs = *reinterpret_cast<const float4*>(zcrow + t);
       }
       l1.x = __builtin_bit_cast(float, il);
       c1.x = __builtin_bit_cast(float, ic);
@@ -1900,6 +1915,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
       const int sc = zslot(t);
       c1 = *reinterpret_cast<const float4*>(ux1 + sc);
       cv = *reinterpret_cast<const float4*>(uv + sc);
+      if (DL) zs = *reinterpret_cast<const float4*>(zcrow + t);
     }
   };
   // Inside the tile loop only the current four tokens are loaded: the two tokens in front of them are the last two of
@@ -1911,7 +1927,10 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     c1 = cv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (TAB) {
       uint32_t ic = 0xFFFFFFFFu;
-      if (p < z_nblk) ic = *reinterpret_cast<const uint32_t*>(tkz + zslot(32 * p + zq4));
+      if (p < z_nblk) {
+        ic = *reinterpret_cast<const uint32_t*>(tkz + zslot(32 * p + zq4));
+        if (DL) zs = *reinterpret_cast<const float4*>(zcrow + 32 * p + zq4);
+      }
       c1.x = __builtin_bit_cast(float, ic);
       return;
     }
@@ -1919,6 +1938,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
       const int sc = zslot(32 * p + zq4);
       c1 = *reinterpret_cast<const float4*>(ux1 + sc);
       cv = *reinterpret_cast<const float4*>(uv + sc);
+      if (DL) zs = *reinterpret_cast<const float4*>(zcrow + 32 * p + zq4);
     }
   };
   auto from_below = [&](float own, float carried) -> float {  // row_shr:1 / row_shl:7 of a DPP row of 16 lanes
@@ -1956,7 +1976,9 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     z[1] = fmaf(wx1_0, l1.w, fmaf(wx1_1, c1.x, fmaf(wx1_2, c1.y, bx1))) * fmaf(wv_0, lv.w, fmaf(wv_1, cv.x, fmaf(wv_2, cv.y, bv)));
     z[2] = fmaf(wx1_0, c1.x, fmaf(wx1_1, c1.y, fmaf(wx1_2, c1.z, bx1))) * fmaf(wv_0, cv.x, fmaf(wv_1, cv.y, fmaf(wv_2, cv.z, bv)));
     z[3] = fmaf(wx1_0, c1.y, fmaf(wx1_1, c1.z, fmaf(wx1_2, c1.w, bx1))) * fmaf(wv_0, cv.y, fmaf(wv_1, cv.z, fmaf(wv_2, cv.w, bv)));
-    if (!(p < z_nblk)) z[0] = z[1] = z[2] = z[3] = 0.f;
+    if (DL) z[0] -= zs.x, z[1] -= zs.y, z[2] -= zs.z, z[3] -= zs.w;
+    // (DL: over the shared row's positions z - z_pad is zero by definition)
+    if (!(p < z_nblk) || (DL && 32 * p + zq4 < z_pv)) z[0] = z[1] = z[2] = z[3] = 0.f;
     // split of 4 values (padded to the 8-wide splitter) -> NP 8-byte stores
     const float z8[8] = {z[0], z[1], z[2], z[3], 0.f, 0.f, 0.f, 0.f};
     svec pl8[NP];
@@ -2100,6 +2122,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   const int sq = (lane & 7) * 4, srs = lane >> 3;
   int s_off[4], s_nblk[4], s_nt4[4];  // per i: the read's slot offset / blocks / owned slots (0: no such read)
   int s_pv[4], s_pad[4];              // SP: positions in front of s_pv[i] live in the shared [PAD] row, at slot s_pad[i] + t
+  int s_db[4];                        // DL: index of the read's position 0 in the Fc rows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rr = a.grp_reads[g * 32 + 8 * i + srs];
@@ -2108,7 +2131,9 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
     s_nt4[i] = rr >= 0 ? (a.ntok[rr] + 3) & ~3 : 0;  // slots the read owns: the tail of its last 32-block is the next read's
     s_pv[i] = SP && rr >= 0 ? a.pv[rr] : 0;
     s_pad[i] = SP && rr >= 0 ? a.padoff[rr] : 0;
+    s_db[i] = DL && rr >= 0 ? a.dbase[rr] : 0;
   }
+  const float* const fcchan = DL ? a.Fc + (int64_t)c * a.dstride : nullptr;
   float* const ychan = a.y + (int64_t)c * a.Tp;
   const float* const x0chan = a.u + (int64_t)c * a.Tp;
   // x0[t - 2 .. t + 3] of a lane's four tokens: the quad and the two values in front of it (TAB: token ids, expanded
@@ -2118,6 +2143,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
   struct XWin {
     float4 cur;  // TAB: cur.x = four ids
     float2 prv;  // TAB: prv.x = two ids
+    float4 f;    // DL: the shared row's convolution at the four positions
   };
   auto x_request = [&](int pp, XWin (&xw)[4]) {
 #pragma unroll
@@ -2132,6 +2158,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
         xw[i].cur = *reinterpret_cast<const float4*>(x0chan + st);
         xw[i].prv = *reinterpret_cast<const float2*>(x0chan + stp);
       }
+      if (DL) xw[i].f = *reinterpret_cast<const float4*>(fcchan + s_db[i] + t);
     }
   };
   XWin xq[2][4];
@@ -2163,10 +2190,17 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
           }
           if (ts == 0) w[0] = w[1] = 0.f;  // Conv1d padding in front of the read
           float4 v = *reinterpret_cast<const float4*>(patch + (8 * i + srs) * PS + sq);
-          v.x = v.x * inv_sc * fmaf(wx0_0, w[0], fmaf(wx0_1, w[1], fmaf(wx0_2, w[2], bx0)));
-          v.y = v.y * inv_sc * fmaf(wx0_0, w[1], fmaf(wx0_1, w[2], fmaf(wx0_2, w[3], bx0)));
-          v.z = v.z * inv_sc * fmaf(wx0_0, w[2], fmaf(wx0_1, w[3], fmaf(wx0_2, w[4], bx0)));
-          v.w = v.w * inv_sc * fmaf(wx0_0, w[3], fmaf(wx0_1, w[4], fmaf(wx0_2, w[5], bx0)));
+          if (DL) {  // + the shared row's own convolution at these positions (the read's z was taken relative to it)
+            v.x = fmaf(v.x, inv_sc, xw.f.x) * fmaf(wx0_0, w[0], fmaf(wx0_1, w[1], fmaf(wx0_2, w[2], bx0)));
+            v.y = fmaf(v.y, inv_sc, xw.f.y) * fmaf(wx0_0, w[1], fmaf(wx0_1, w[2], fmaf(wx0_2, w[3], bx0)));
+            v.z = fmaf(v.z, inv_sc, xw.f.z) * fmaf(wx0_0, w[2], fmaf(wx0_1, w[3], fmaf(wx0_2, w[4], bx0)));
+            v.w = fmaf(v.w, inv_sc, xw.f.w) * fmaf(wx0_0, w[3], fmaf(wx0_1, w[4], fmaf(wx0_2, w[5], bx0)));
+          } else {
+            v.x = v.x * inv_sc * fmaf(wx0_0, w[0], fmaf(wx0_1, w[1], fmaf(wx0_2, w[2], bx0)));
+            v.y = v.y * inv_sc * fmaf(wx0_0, w[1], fmaf(wx0_1, w[2], fmaf(wx0_2, w[3], bx0)));
+            v.z = v.z * inv_sc * fmaf(wx0_0, w[2], fmaf(wx0_1, w[3], fmaf(wx0_2, w[4], bx0)));
+            v.w = v.w * inv_sc * fmaf(wx0_0, w[3], fmaf(wx0_1, w[4], fmaf(wx0_2, w[5], bx0)));
+          }
           *reinterpret_cast<float4*>(ychan + s_off[i] + ts) = v;
         }
       }
@@ -2185,7 +2219,7 @@ __global__ __launch_bounds__(256, CB == 16 ? DC_H3_OCC16 : DC_H3_OCC) void hyena
 #endif
 }
 
-template <int MODE, bool TAB, bool SP>
+template <int MODE, bool TAB, int SP>
 static int launch_hyena3_t(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   const size_t lds = (size_t)h3_filt_bytes(SplitMode<MODE>::NP) + 2 * h3_zbuf_bytes(SplitMode<MODE>::NP);
   DC_SET_MAX_SMEM_ONCE_PER_DEVICE((hyena3_kernel<32, MODE, TAB, SP>), lds);
@@ -2210,12 +2244,14 @@ int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P) {
   // fp16 planes, 64 with the bf16 ones; DC_H3_WS=0 keeps hyena3_kernel (A/B, parity)
   const char* ws_env = getenv("DC_H3_WS");
   const bool ws_on = !(ws_env && atoi(ws_env) == 0) && !getenv("DC_H3_CB16");
-  const bool sp = a.pv != nullptr;
+  const int sp = a.pv == nullptr ? 0 : (a.dbase == nullptr ? 1 : 2);
   if (sp) DC_REQUIRE(a.padoff, "shared [PAD] prefix: pv without padoff");
+  if (sp == 2) DC_REQUIRE(a.zc && a.Fc && a.dstride > 0, "shared [PAD] prefix, linear form: dbase without zc / Fc");
   // (mode, table gather, shared prefix) -> instantiation
-#define DC_H_DISPATCH(fn, MODE)                                                                                   \
-  return sp ? (tab ? fn<MODE, true, true>(st, a, n_groups, max_P) : fn<MODE, false, true>(st, a, n_groups, max_P)) \
-            : (tab ? fn<MODE, true, false>(st, a, n_groups, max_P) : fn<MODE, false, false>(st, a, n_groups, max_P))
+#define DC_H_DISPATCH(fn, MODE)                                                                                              \
+  return sp == 2 ? (tab ? fn<MODE, true, 2>(st, a, n_groups, max_P) : fn<MODE, false, 2>(st, a, n_groups, max_P))               \
+                 : (sp == 1 ? (tab ? fn<MODE, true, 1>(st, a, n_groups, max_P) : fn<MODE, false, 1>(st, a, n_groups, max_P))    \
+                            : (tab ? fn<MODE, true, 0>(st, a, n_groups, max_P) : fn<MODE, false, 0>(st, a, n_groups, max_P)))
   if (a.split_mode == 1) {
     DC_REQUIRE(a.kfp_f16 && a.ch_inv_scale && a.overflow, "fp16x3 long convolution needs its planes / scales / guard");
     if (ws_on && max_P <= 32 * h4_max_chunks(2)) DC_H_DISPATCH(launch_hyena4_t, 1);
@@ -2400,6 +2436,43 @@ int launch_fill_pad_logits(hipStream_t st, const void* ids, int ids_i64, const f
   else
     hipLaunchKernelGGL(fill_pad_logits_kernel<uint8_t>, grid, dim3(256), 0, st, (const uint8_t*)ids, quals, fill_dst, fill_n,
                        fill_src, padlog, pad_id, logits, bad);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+// Linear form of the shared [PAD] prefix: the shared row has just been through its long-convolution kernel with a UNIT output
+// gate (short-filter taps of x0 zeroed, bias 1), so its y slots hold F = k * z_pad.  Per (channel, position): F and the gated
+// input z_pad go to the rows the reads' kernels subtract / add from (behind the zero stretch `z0`), and y gets its real value
+// F * gate -- the same fma chains, in the same order, as the long-convolution kernels' own.
+__global__ __launch_bounds__(256) void pad_row_finish_kernel(const float* __restrict__ u, const float* __restrict__ tab, int pad_id,
+                                                             int D, int64_t Tp, int pad_toff, int L, const float* __restrict__ sw,
+                                                             const float* __restrict__ sb, float* __restrict__ y,
+                                                             float* __restrict__ zc, float* __restrict__ Fc, int64_t dstride, int z0) {
+  const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (t >= L) return;
+  auto sf = [&](int k3) -> float {  // short causal filter of row group k3 (0 x0, 1 x1, 2 v) at position t, Conv1d padding in front
+    float w[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tt = t - 2 + j;
+      w[j] = tt < 0 ? 0.f : (tab ? tab[(int64_t)pad_id * 3 * D + k3 * D + c] : u[(int64_t)(k3 * D + c) * Tp + pad_toff + tt]);
+    }
+    const float* f = sw + (int64_t)(k3 * D + c) * 3;
+    return fmaf(f[0], w[0], fmaf(f[1], w[1], fmaf(f[2], w[2], sb[k3 * D + c])));
+  };
+  const float z = sf(1) * sf(2), g = sf(0);
+  float* yp = y + (int64_t)c * Tp + pad_toff + t;
+  const float F = *yp;
+  zc[(int64_t)c * dstride + z0 + t] = z;
+  Fc[(int64_t)c * dstride + z0 + t] = F;
+  *yp = F * g;
+}
+
+int launch_pad_row_finish(hipStream_t st, const float* u, const float* tab, int pad_id, int D, int64_t Tp, int pad_toff, int L,
+                          const float* sw, const float* sb, float* y, float* zc, float* Fc, int64_t dstride, int z0) {
+  if (L <= 0) return DC_OK;
+  hipLaunchKernelGGL(pad_row_finish_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)D), dim3(256), 0, st, u, tab, pad_id, D, Tp,
+                     pad_toff, L, sw, sb, y, zc, Fc, dstride, z0);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

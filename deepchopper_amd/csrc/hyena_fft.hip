@@ -242,7 +242,7 @@ __global__ __launch_bounds__((1 << LOGM) / 16) void hyena_fft_filter_kernel(cons
 // ---------------------------------------------------------------------------------------------------
 // the operator for one (read, channel)
 // ---------------------------------------------------------------------------------------------------
-template <int LOGM, bool TAB, bool SP>  // SP: reads with a shared [PAD] prefix (HyenaArgs::pv / padoff)
+template <int LOGM, bool TAB, int SP>  // SP: 1 = reads with a shared [PAD] prefix (HyenaArgs::pv / padoff), 2 = its linear form (+ dbase / zc / Fc)
 __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
                                                                        const float2* __restrict__ tw,
                                                                        const float2* __restrict__ spec) {
@@ -254,8 +254,11 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
   const int toff = a.toff[r];
   const int L = a.ntok[r];
   const int D = a.D;
+  constexpr bool DL = SP == 2;  // y = (k * (z - z_pad) + F) * gate: the transform covers the read's own positions only
   const int pv = SP ? a.pv[r] : 0, padoff = SP ? a.padoff[r] : 0;  // positions < pv live in the shared [PAD] row (pv: a multiple of 4)
   auto slot = [&](int t) -> int { return (SP && t < pv ? padoff : toff) + t; };
+  const float* zcrow = DL ? a.zc + (int64_t)c * a.dstride + a.dbase[r] : nullptr;  // the shared row's z / convolution at the read's positions
+  const float* fcrow = DL ? a.Fc + (int64_t)c * a.dstride + a.dbase[r] : nullptr;
   const float* ux0 = a.u + (int64_t)c * a.Tp;
   const float* ux1 = a.u + (int64_t)(D + c) * a.Tp;
   const float* uv = a.u + (int64_t)(2 * D + c) * a.Tp;
@@ -341,16 +344,19 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
       continue;
     }
     Raw r1[UB], rv[UB];
+    float2 zsub[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int t = 2 * (tid + (j0 + u) * T);
       r1[u] = raw_load(ux1, t);
       if (!TAB) rv[u] = raw_load(uv, t);
+      if (DL) zsub[u] = *reinterpret_cast<const float2*>(zcrow + (t < t_last ? t : t_last));
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int t = 2 * (tid + (j0 + u) * T);
       v2f z = sc_eval(1, r1[u]) * sc_eval(2, TAB ? r1[u] : rv[u]);
+      if (DL) z = t < pv ? v2f{0.f, 0.f} : z - V(zsub[u]);  // (over the shared row's positions z - z_pad is zero by definition)
       if (t >= L) z = v2f{0.f, 0.f};
       else if (t + 1 >= L) z.y = 0.f;
       s_me[(j0 + u) * PSTEP] = F(z);
@@ -415,13 +421,20 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
   for (int j0 = 0; j0 < NIT; j0 += UB) {
     if (2 * (j0 * T) >= L) break;  // block-uniform: nothing of the read is left in this batch
     Raw r0[UB];
+    float2 fadd[UB];
 #pragma unroll
-    for (int u = 0; u < UB; ++u) r0[u] = raw_load(ux0, 2 * (tid + (j0 + u) * T));
+    for (int u = 0; u < UB; ++u) {
+      const int t = 2 * (tid + (j0 + u) * T);
+      r0[u] = raw_load(ux0, t);
+      if (DL) fadd[u] = *reinterpret_cast<const float2*>(fcrow + (t < t_last ? t : t_last));
+    }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int t = 2 * (tid + (j0 + u) * T);
       const v2f rv = V(s_me[(j0 + u) * PSTEP]);
-      const v2f o = rv * v2f{inv_m, -inv_m} * sc_eval(0, r0[u]);
+      v2f cv = rv * v2f{inv_m, -inv_m};
+      if (DL) cv += V(fadd[u]);  // + the shared row's own convolution (the read's z was taken relative to it)
+      const v2f o = cv * sc_eval(0, r0[u]);
       if (t < L && t >= pv) {  // (SP: own positions only)
         if (t + 1 < L) {
           *reinterpret_cast<float2*>(y + t) = F(o);
@@ -450,8 +463,10 @@ __global__ __launch_bounds__((1 << LOGM) / 16, 4) void hyena_fft_kernel(HyenaArg
 constexpr int F15_LOGM = 15, F15_M = 1 << F15_LOGM, F15_N2 = 2048, F15_ROW = F15_N2 + F15_N2 / 16;  // padded row (float2)
 
 // short causal filter + gating helpers of one (read, channel) (the same arithmetic as hyena_fft_kernel's lambdas)
-template <bool TAB, bool SP>
+template <bool TAB, int SP>
 struct GateSrc {
+  static constexpr bool DL = SP == 2;
+  const float *zcrow, *fcrow;  // DL: the shared row's z / convolution at the read's positions
   const float *ux0, *ux1, *uv;
   const unsigned char* tok;
   const float* s_tab;
@@ -466,6 +481,8 @@ struct GateSrc {
     toff = a.toff[r];
     pv = SP ? a.pv[r] : 0;
     padoff = SP ? a.padoff[r] : 0;
+    zcrow = DL ? a.zc + (int64_t)c * a.dstride + a.dbase[r] : nullptr;
+    fcrow = DL ? a.Fc + (int64_t)c * a.dstride + a.dbase[r] : nullptr;
     L = a.ntok[r];
     t_last = L > 0 ? (L - 1) & ~1 : 0;
     ux0 = a.u + (int64_t)c * a.Tp;
@@ -525,6 +542,7 @@ struct GateSrc {
     const Raw r1 = raw_load(ux1, t);
     const Raw rv = TAB ? r1 : raw_load(uv, t);
     v2f z = sc_eval(1, r1) * sc_eval(2, rv);
+    if (DL) z = t < pv ? v2f{0.f, 0.f} : z - V(*reinterpret_cast<const float2*>(zcrow + (t < t_last ? t : t_last)));
     if (t >= L) z = v2f{0.f, 0.f};
     else if (t + 1 >= L) z.y = 0.f;
     return z;
@@ -569,7 +587,7 @@ __device__ __forceinline__ void f15_forward_rows(float2* s0, float2* s1, int ka,
   fft_lds<11>(tid < 128 ? s0 : s1, tw, tid & 127);
 }
 
-template <bool TAB, bool SP>
+template <bool TAB, int SP>
 __global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int32_t* __restrict__ reads, const float2* __restrict__ tw,
                                                           const float2* __restrict__ spec, float2* __restrict__ scratch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw15[];
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_kernel(HyenaArgs a, const int
 }
 
 // second kernel: r[b + 2048 a] = sum_k1 scratch[k1][b] W16^(k1 a); y[t] = conv[t] * shortconv(x0)[t]
-template <bool TAB, bool SP>
+template <bool TAB, int SP>
 __global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
                                                               const float2* __restrict__ scratch) {
   __shared__ float s_tab[64];
@@ -685,6 +703,7 @@ __global__ __launch_bounds__(256) void hyena_fft15_out_kernel(HyenaArgs a, const
         const v2f z0 = g.z_pair(0);
         conv.x = fmaf(a.kf[(int64_t)c * a.kf_stride + F15_M], z0.x, conv.x);
       }
+      if (SP == 2) conv += V(*reinterpret_cast<const float2*>(g.fcrow + t));  // + the shared row's own convolution
       const v2f o = conv * g.sc_eval(0, g.raw_load(g.ux0, t));
       if (t + 1 < L) *reinterpret_cast<float2*>(y + t) = F(o);
       else y[t] = o.x;
@@ -751,7 +770,7 @@ int launch_filter_t(hipStream_t st, const float* kf, int64_t kf_stride, int kf_t
   return DC_OK;
 }
 
-template <int LOGM, bool TAB, bool SP>
+template <int LOGM, bool TAB, int SP>
 int launch_fft_t2(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
   constexpr int T = (1 << LOGM) / 16;
   DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fft_kernel<LOGM, TAB, SP>), fft_smem<LOGM>());
@@ -761,7 +780,8 @@ int launch_fft_t2(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int 
 }
 template <int LOGM, bool TAB>
 int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
-  return a.pv ? launch_fft_t2<LOGM, TAB, true>(st, a, reads, n_reads, tw, spec) : launch_fft_t2<LOGM, TAB, false>(st, a, reads, n_reads, tw, spec);
+  if (a.pv && a.dbase) return launch_fft_t2<LOGM, TAB, 2>(st, a, reads, n_reads, tw, spec);
+  return a.pv ? launch_fft_t2<LOGM, TAB, 1>(st, a, reads, n_reads, tw, spec) : launch_fft_t2<LOGM, TAB, 0>(st, a, reads, n_reads, tw, spec);
 }
 
 }  // namespace
@@ -810,12 +830,15 @@ int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads,
     DC_LAUNCH_CHECK();                                                                                                  \
     hipLaunchKernelGGL((hyena_fft15_out_kernel<TAB, SP>), grid, block, 0, st, a, reads, (const float2*)sc);             \
   } while (0)
+  const int sp = a.pv == nullptr ? 0 : (a.dbase == nullptr ? 1 : 2);
   if (a.tok) {
-    if (a.pv) DC_F15_LAUNCH(true, true);
-    else DC_F15_LAUNCH(true, false);
+    if (sp == 2) DC_F15_LAUNCH(true, 2);
+    else if (sp == 1) DC_F15_LAUNCH(true, 1);
+    else DC_F15_LAUNCH(true, 0);
   } else {
-    if (a.pv) DC_F15_LAUNCH(false, true);
-    else DC_F15_LAUNCH(false, false);
+    if (sp == 2) DC_F15_LAUNCH(false, 2);
+    else if (sp == 1) DC_F15_LAUNCH(false, 1);
+    else DC_F15_LAUNCH(false, 0);
   }
 #undef DC_F15_LAUNCH
   DC_LAUNCH_CHECK();

@@ -6,6 +6,7 @@ copies.  All arithmetic happens inside libdeepchopper_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -244,6 +245,7 @@ class HipModel:
         mode = C.c_int32()
         _lib.check(_lib.lib().dc_model_get_gemm_mode(self._h, C.byref(mode)))  # $DC_GEMM_MODE is parsed by the library only
         self.gemm_mode = GEMM_MODES[mode.value]
+        self.prefix_mode = "linear" if os.environ.get("DC_PREFIX_MODE") in ("linear", "2") else "exact"  # (the library reads the same variable)
         del keep
 
     def close(self):
@@ -297,6 +299,13 @@ class HipModel:
             self._h, _stream(), _ptr(input_ids), int(input_ids.dtype == torch.int64), _ptr(input_quals), n, row_stride,
             first.ctypes.data_as(i32p), n_tokens.ctypes.data_as(i32p), n_pad.ctypes.data_as(i32p), int(pad_token_id), _ptr(out)))
         return out
+
+    def set_prefix_mode(self, mode: str) -> None:
+        """How `forward_shared_prefix` shares the pad runs: "exact" (the long convolution still walks every row's padded
+        sequence; bit-identical to the padded launch on the block-Toeplitz forms) or "linear" (y = (k * (z - z_pad) + F) * gate:
+        the long convolution covers a row's own tokens only; equal to fp32 rounding)."""
+        _lib.check(_lib.lib().dc_model_set_prefix_mode(self._h, {"exact": 1, "linear": 2}[mode]))
+        self.prefix_mode = mode
 
     def prefix_violations(self) -> int:
         """Declared pad positions of `forward_shared_prefix` launches that did not hold ([PAD], 0.0) (synchronises)."""

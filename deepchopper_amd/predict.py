@@ -73,6 +73,12 @@ class PredictPipeline:
         # reference_padding: rows share their [PAD] prefix (dc_forward_shared_prefix) instead of running it once per row;
         # DC_SHARED_PREFIX=0 keeps the padded launches (A/B, parity tests)
         self.shared_prefix = os.environ.get("DC_SHARED_PREFIX", "1") != "0"
+        # ... in the linear form by default (y = (k * (z - z_pad) + F) * gate: the long convolution covers a read's own tokens,
+        # not its batch's longest read; equal to the padded launch to fp32 rounding, tests/test_gpu_forward.py);
+        # DC_PREFIX_MODE=exact keeps the form that is bit-identical to the padded launch on the block-Toeplitz kernels
+        net = getattr(model, "net", None)
+        if net is not None and hasattr(net, "set_prefix_mode"):
+            net.set_prefix_mode("exact" if os.environ.get("DC_PREFIX_MODE", "linear") in ("exact", "1") else "linear")
 
     # ---- stage 1 ---------------------------------------------------------------------
     def tokenize(self, seq: torch.Tensor, qual: torch.Tensor, offsets: torch.Tensor, max_len_bases: int,

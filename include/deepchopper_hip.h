@@ -260,6 +260,19 @@ int dc_forward_shared_prefix(dc_model* m, void* stream, const void* d_input_ids,
                              const int32_t* h_first, const int32_t* h_n_tokens, const int32_t* h_n_pad,
                              int32_t pad_token_id, float* d_logits);
 
+/* How dc_forward_shared_prefix shares the pad runs.
+ *   1 (default) exact form: as described above -- one shared row per long-convolution form; the long convolution of a
+ *     row still walks its whole padded sequence (reading the pad positions from the shared row).  Bit-identical to
+ *     dc_forward_ragged on the padded rows wherever every row takes a block-Toeplitz form.
+ *   2 linear form: the long convolution is linear, so with ONE shared row (as long as the longest padded row) giving
+ *     z_pad (its gated input) and F = k * z_pad, a row's output is ((k * (z - z_pad)) + F) * gate and z - z_pad is zero
+ *     over the row's whole pad run: the long convolution starts 4 positions in front of the row's own tokens and costs
+ *     what it costs without padding (O(n^2) / O(n log n) in the READ's length, not the batch's longest).  Same
+ *     mathematics, another summation order: logits agree with the exact form to fp32 rounding (~1e-5 on O(1) logits;
+ *     tests hold it to 2e-4), not bit for bit.
+ * $DC_PREFIX_MODE = exact | linear sets the initial mode of a handle. */
+int dc_model_set_prefix_mode(dc_model* m, int32_t mode);
+
 /* Wavefronts of dc_forward_shared_prefix's copy pass that met a declared pad position not holding
  * (pad_token_id, 0.0) since the last call; synchronises `stream`, resets the counter.  Non-zero = the caller broke the
  * contract and the logits of that launch are not those of the padded batch. */

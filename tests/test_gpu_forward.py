@@ -759,6 +759,7 @@ def test_shared_prefix_equals_the_padded_launch(env, case):
     ids, q, first, ntok, npad = _padded_launch(rng, build(rng))
     d_ids, d_q = ops.to_device(ids), ops.to_device(q)
     padded = model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()
+    model.set_prefix_mode("exact")
     model.set_profiling(True)
     model.profile_reset()
     try:
@@ -823,3 +824,81 @@ def test_shared_prefix_contract_violation_is_counted(env):
     assert model.prefix_violations() > 0
     with pytest.raises(Exception, match="pad run must be shorter"):
         model.forward_shared_prefix(ops.to_device(ids), ops.to_device(q), first, ntok, ntok)
+
+
+@pytest.mark.parametrize("case", list(SHARED_PREFIX_CASES))
+def test_shared_prefix_linear_form_equals_the_padded_launch(env, case):
+    """The linear form (dc_model_set_prefix_mode 2, VERDICT r4 next #1 "stretch" taken one step further): the long
+    convolution is linear, so with ONE shared [PAD] row giving z_pad and F = k * z_pad a row is
+    y = ((k * (z - z_pad)) + F) * gate with z - z_pad = 0 over its pad run -- the long convolution covers the read's own
+    tokens, whatever the batch's longest read.  Same mathematics in another summation order: held to the parity
+    tolerance against the padded launch over real tokens AND pad columns, in every GEMM mode, and the long-convolution
+    class of a row follows ITS length (a short read in a long batch stays on the block-Toeplitz kernel)."""
+    torch, ops, sd, model = env
+    build, _ = SHARED_PREFIX_CASES[case]
+    rng = np.random.default_rng(len(case))
+    batches = build(rng)
+    ids, q, first, ntok, npad = _padded_launch(rng, batches)
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    padded = model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()
+    model.set_prefix_mode("linear")
+    model.set_profiling(True)
+    model.profile_reset()
+    try:
+        lin = model.forward_shared_prefix(d_ids, d_q, first, ntok, npad).cpu().numpy()
+        stages = model.profile()
+        again = model.forward_shared_prefix(d_ids, d_q, first, ntok, npad).cpu().numpy()
+    finally:
+        model.set_profiling(False)
+        model.set_prefix_mode("exact")
+    assert model.prefix_violations() == 0
+    assert np.isfinite(lin).all() and np.array_equal(lin, again)
+    mask = np.zeros(ids.shape, bool)
+    for r in range(len(ntok)):
+        mask[r, first[r]: first[r] + ntok[r]] = True
+    assert np.array_equal(lin[~mask], padded[~mask])
+    d = np.abs(lin - padded)[mask]
+    assert d.max() <= ATOL, f"{case} ({model.gemm_mode}): max |d| = {d.max():.3e}"
+    print(f"linear form vs padded launch, {case} ({model.gemm_mode}): max |dlogit| = {d.max():.2e}")
+    if npad.max() >= 4:
+        assert stages.get("hyena_pad_row", (0, 0))[1] == 4, stages  # one shared row, once per layer
+        # FFT launches: one per layer and transform size among the reads THEMSELVES
+        own = np.array([x for b in batches for x in b]) + 4
+        sizes = {int(np.ceil(np.log2(max(n, 1024)))) for n in own[(npad >= 4) & (own > 2560)]} | {
+            int(np.ceil(np.log2(max(n, 1024)))) for n in ntok[(npad < 4) & (ntok > 2560)]}
+        small = len({z for z in sizes if z <= 14})
+        assert stages.get("hyena_fft", (0, 0))[1] == 4 * small, (stages, sizes)  # (the shared row's own launch is inside "hyena_pad_row")
+
+
+def test_shared_prefix_forms_error_vs_float64(hip_lib):
+    """Which of them is nearer the truth?  A left-padded batch whose longest row takes an FFT form, against a float64
+    evaluation of the oracle on the padded batch: the padded launch, the exact shared-prefix form, the linear form and
+    the torch-fp32 oracle itself.  The linear form transforms the reads' own tokens only (shorter transforms, the short
+    rows on the exactly causal block-Toeplitz kernel), so its error must not exceed the padded launch's by more than
+    fp32 noise -- the differences between the forms that the tests above bound by 2e-4 are rounding, not signal."""
+    import torch
+
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = synthetic_state_dict(3)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    rng = np.random.default_rng(64)
+    ids, q, first, ntok, npad = _padded_launch(rng, [[5200, 700, 1900, 3100]])
+    ref64 = fr.forward(sd, ids.astype(np.int64), q, dtype=torch.float64).numpy()
+    ref32 = fr.forward(sd, ids.astype(np.int64), q).numpy()
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    errs = {"oracle_f32": float(np.abs(ref32 - ref64).max())}
+    for mode in ("f32", "bf16x6", "fp16x3"):
+        model.set_gemm_mode(mode)
+        errs[f"{mode}/padded"] = float(np.abs(model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy() - ref64).max())
+        for form in ("exact", "linear"):
+            model.set_prefix_mode(form)
+            out = model.forward_shared_prefix(d_ids, d_q, first, ntok, npad).cpu().numpy()
+            errs[f"{mode}/{form}"] = float(np.abs(out - ref64).max())
+    print("max |logit - float64 oracle| on a left-padded batch (longest row 5 200 tokens):", errs)
+    for mode in ("f32", "bf16x6", "fp16x3"):
+        assert errs[f"{mode}/linear"] <= 1.5 * max(errs[f"{mode}/padded"], errs["oracle_f32"]) + 2e-5, errs
+        assert errs[f"{mode}/exact"] <= 1.5 * max(errs[f"{mode}/padded"], errs["oracle_f32"]) + 2e-5, errs
+        assert errs[f"{mode}/linear"] < ATOL and errs[f"{mode}/padded"] < ATOL
