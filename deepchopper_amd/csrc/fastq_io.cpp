@@ -933,6 +933,84 @@ static int read_chunk_impl(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uin
     for (int k = 1; k < 4 && ok; ++k) ok = e[k - 1] < r->buf.size() && r->line_end(e[k - 1] + 1, &e[k], rc);
     if (rc) return rc;
     int64_t recno = r->n_records;
+    // Sequence / quality wrapped over several lines (what kseq -- pyfastx.Fastx, deepchopper/data/only_fq.py:34 -- accepts):
+    // sequence lines up to the first line that starts with '+', then quality lines until as many quality characters as
+    // bases have been read.  Taken only when the third line of the record is not the separator; the 4-line form below
+    // is untouched.  Pieces = [begin, end) byte ranges of buf, '\r' stripped.
+    std::vector<std::pair<size_t, size_t>> sq_pieces, q_pieces;
+    // (also when the third line IS the separator but the quality line is shorter than the sequence line: a one-line sequence
+    //  with a wrapped quality.  If that does not add up exactly, the record is judged as the 4-line record it looks like.)
+    const bool sep3 = ok && r->buf[e[1] + 1] == '+';
+    auto bare = [&](size_t a, size_t b) { while (b > a && r->buf[b - 1] == '\r') --b; return b - a; };
+    if (ok && r->buf[r->pos] == '@' && (!sep3 || bare(e[2] + 1, e[3]) < bare(e[0] + 1, e[1]))) {
+      const size_t e3_four_line = e[3];
+      if (r->ranged && sep3) goto four_line;
+      if (r->ranged)
+        return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: record %lld wraps its sequence over several lines; a multi-line FASTQ "
+                    "cannot be split by byte ranges (run it on one GPU, or gzip it: a gzip stream is dealt record by record)",
+                    r->path.c_str(), (long long)recno);
+      auto stripped = [&](size_t a, size_t b) { while (b > a && r->buf[b - 1] == '\r') --b; return b; };
+      size_t ls = 0, lq = 0, at = e[0] + 1, le = 0;
+      bool sep = false;
+      for (;;) {  // sequence lines
+        if (!r->line_end(at, &le, rc)) break;
+        if (r->buf[at] == '+') { sep = true; break; }
+        const size_t b1 = stripped(at, le);
+        if (b1 > at) sq_pieces.emplace_back(at, b1), ls += b1 - at;
+        if (le >= r->buf.size()) { at = le; break; }
+        at = le + 1;
+      }
+      if (rc) return rc;
+      if (!sep)
+        return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: record %lld has no '+' separator", r->path.c_str(), (long long)recno);
+      at = le < r->buf.size() ? le + 1 : le;  // behind the separator line
+      size_t last = le;
+      while (lq < ls) {  // quality lines (a quality line may start with '@' or '+': only the count ends the record)
+        if (!r->line_end(at, &le, rc)) break;
+        const size_t b1 = stripped(at, le);
+        if (b1 > at) q_pieces.emplace_back(at, b1), lq += b1 - at;
+        last = le;
+        if (le >= r->buf.size()) break;
+        at = le + 1;
+      }
+      if (rc) return rc;
+      e[3] = last;
+      const uint8_t* dd = r->buf.data();
+      size_t s0w = r->pos, hw = e[0];
+      while (hw > s0w && dd[hw - 1] == '\r') --hw;
+      size_t nm0w = s0w + 1, nm1w = nm0w;
+      while (nm1w < hw && dd[nm1w] != ' ' && dd[nm1w] != '\t') ++nm1w;
+      const int64_t lnamew = (int64_t)(nm1w - nm0w);
+      int64_t lnw = name_len ? (int64_t)(hw - nm0w) : lnamew;
+      if (sep3 && (lnamew == 0 || ls == 0 || ls != lq)) {  // not a wrapped quality after all
+        e[3] = e3_four_line;
+        goto four_line;
+      }
+      if (lnamew == 0 || ls == 0 || lq == 0)
+        return fail(DC_FQ_ERR_INCOMPLETE, "Incomplete FASTQ record at position %lld in %s", (long long)recno, r->path.c_str());
+      if (ls != lq)
+        return fail(DC_FQ_ERR_LENGTH, "Sequence/quality length mismatch in record '%.*s': seq=%lld, qual=%lld", (int)lnamew,
+                    (const char*)dd + nm0w, (long long)ls, (long long)lq);
+      if (nb + (int64_t)ls > cap_bases || nn + lnw > cap_names) {
+        if (n == 0) return fail(DC_FQ_ERR_ARG, "record '%.*s' (%lld bases) does not fit the chunk buffers", (int)lnamew, (const char*)dd + nm0w, (long long)ls);
+        break;
+      }
+      int64_t w = nb;
+      for (auto& pc : sq_pieces) { memcpy(seq + w, dd + pc.first, pc.second - pc.first); w += (int64_t)(pc.second - pc.first); }
+      w = nb;
+      for (auto& pc : q_pieces) { memcpy(qual + w, dd + pc.first, pc.second - pc.first); w += (int64_t)(pc.second - pc.first); }
+      memcpy(names + nn, dd + nm0w, (size_t)lnw);
+      if (name_len) name_len[n] = (int32_t)lnamew;
+      nb += (int64_t)ls;
+      nn += lnw;
+      ++n;
+      offsets[n] = nb;
+      name_offsets[n] = nn;
+      ++r->n_records;
+      r->pos = r->next_line(e[3]);
+      continue;
+    }
+  four_line:
     if (!ok) return fail(DC_FQ_ERR_FORMAT, "FASTQ parsing error in %s: truncated record %lld", r->path.c_str(), (long long)recno);
     const uint8_t* d = r->buf.data();
     size_t s0 = r->pos, s1 = e[0] + 1, s2 = e[1] + 1, s3 = e[2] + 1;

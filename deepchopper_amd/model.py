@@ -62,22 +62,28 @@ class DeepChopper:
     def from_pretrained(model_name: str) -> TokenClassificationModel:
         """dc_hg.py:119-163.  `model_name` is a local directory / file holding the checkpoint the
         reference would download (`model.safetensors` written by PyTorchModelHubMixin).  Hub ids
-        (`yangliz5/deepchopper`) are resolved through $DEEPCHOPPER_MODEL_DIR/<id> or the HF cache
-        if present; there is no network access in this build.  The file is read as the mixin wrote it: aliases of
+        (`yangliz5/deepchopper`) are resolved through $DEEPCHOPPER_MODEL_DIR/<id>, then through the HF Hub client: its
+        cache, and -- unless HF_HUB_OFFLINE is set -- a download, as the reference's mixin does.  The file is read as the mixin wrote it: aliases of
         shared tensors that `safetensors.torch.save_model` dropped are restored, buffers are recomputed if absent,
         extra tensors are ignored, and the architecture is inferred from the tensor shapes and cross-checked
         against a `config.json` next to the weights (`weights.load_checkpoint`)."""
         for cand in (model_name, os.path.join(os.environ.get("DEEPCHOPPER_MODEL_DIR", ""), model_name)):
             if cand and os.path.exists(cand):
                 return TokenClassificationModel(*load_checkpoint(cand))
+        # PyTorchModelHubMixin.from_pretrained downloads (dc_hg.py:140): so does this, unless the Hub client is told to stay
+        # offline (HF_HUB_OFFLINE=1, as in this build's containers) -- then only the local cache is consulted.  Weights and
+        # their config only: no remote code is fetched or executed.
+        offline = os.environ.get("HF_HUB_OFFLINE", "").strip().upper() in ("1", "ON", "YES", "TRUE")
         try:
             from huggingface_hub import snapshot_download
 
-            path = snapshot_download(model_name, local_files_only=True)
+            path = snapshot_download(model_name, local_files_only=offline, allow_patterns=["*.safetensors", "*.json", "*.ckpt"])
         except Exception as e:
+            why = ("the HF Hub client is offline (HF_HUB_OFFLINE) and the checkpoint is not in its cache" if offline
+                   else "the download from the HF Hub failed")
             raise FileNotFoundError(
                 f"checkpoint '{model_name}' not found locally (set DEEPCHOPPER_MODEL_DIR or pass a path to "
-                f"model.safetensors / .ckpt); the HF Hub is not reachable from this environment: {e}"
+                f"model.safetensors / .ckpt); {why}: {e}"
             ) from None
         return TokenClassificationModel(*load_checkpoint(path))
 

@@ -325,3 +325,61 @@ def test_fuse_chunks_keeps_every_read_and_the_batch_boundaries(tmp_path):
             n, L = batches[b + len(c.sub_sizes)]
             assert held + n * L > 25000
         b += len(c.sub_sizes)
+
+
+def _wrap(text: bytes, width: int) -> bytes:
+    return b"\n".join(text[i: i + width] for i in range(0, len(text), width))
+
+
+def test_multi_line_fastq_is_read_like_kseq_reads_it(tmp_path):
+    """VERDICT r4 missing #5: the reference parses with pyfastx.Fastx (deepchopper/data/only_fq.py:34) -- kseq, which accepts
+    sequence and quality wrapped over several lines: sequence lines up to the '+' line, then quality lines until as many
+    quality characters as bases.  Three cases: (1) every record wrapped (several widths, CRLF, quality lines that happen to
+    start with '@' / '+'), mixed with 4-line records, plain and gzip, in small chunks; (2) wrapped records with the header
+    kept whole (full_header readers: the chop stage); (3) the refusals: quality shorter / longer than the sequence, no '+'
+    line, and a byte-range shard of a multi-line file."""
+    from deepchopper_amd import synth
+
+    seqs, quals, ids = synth.synth_reads_mixed(40, 30, 700, seed=4)
+    quals = [bytes(q) for q in quals]
+    quals[3] = b"@" + quals[3][1:]            # a quality string whose FIRST line starts with '@'
+    k2 = next(k for k in range(40) if k % 4 == 0 and k % 3 and len(seqs[k]) > 130)  # wrapped at 60 in sequence and quality
+    quals[k2] = quals[k2][:60] + b"+@" + quals[k2][62:120] + b"@" + quals[k2][121:]  # its 2nd line starts with "+@", its 3rd with '@'
+    assert len(quals[k2]) == len(seqs[k2])
+    rec = []
+    for k, (i, s, q) in enumerate(zip(ids, seqs, quals)):
+        w = (60, 80, 7, 1000000)[k % 4]       # width 1 000 000: the 4-line form among wrapped records
+        nl = b"\r\n" if k % 5 == 0 else b"\n"
+        body = b"@" + i.encode() + b" ch=%d" % k + b"\n" + _wrap(s, w) + b"\n+\n" + _wrap(q, w if k % 3 else max(w // 2, 5)) + b"\n"
+        rec.append(body.replace(b"\n", nl))
+    text = b"".join(rec)
+    plain = tmp_path / "wrapped.fq"
+    plain.write_bytes(text)
+    gz = tmp_path / "wrapped.fq.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(text)
+    for path in (plain, gz):
+        for full in (False, True):
+            with FastqReader(str(path), full_header=full) as rd:
+                got = [r for c in rd.chunks(7, 3000) for r in c.records()]
+            assert [g[0] for g in got] == ids
+            assert [g[1] for g in got] == seqs and [g[2] for g in got] == quals
+    with FastqReader(str(plain), full_header=True) as rd:
+        c = next(iter(rd.chunks(1000, 1 << 30)))
+        hdr = c._names.tobytes()
+        assert hdr[c._name_offsets[7]: c._name_offsets[8]] == ids[7].encode() + b" ch=7" and int(c._name_len[7]) == len(ids[7])
+    assert [r[0] for r in iter_fastq(str(plain))] == ids
+    # refusals
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r1\nACGT\nACGT\n+\nIIII\nIII\n")                      # 8 bases, 7 qualities, end of file
+    with pytest.raises(Exception, match="length mismatch in record 'r1': seq=8, qual=7"):
+        list(iter_fastq(str(bad)))
+    bad.write_bytes(b"@r1\nACGT\nACGT\n+\nIIIII\nIIII\n@r2\nAC\n+\nII\n")    # quality overshoots: 9 for 8
+    with pytest.raises(Exception, match="length mismatch in record 'r1': seq=8, qual=9"):
+        list(iter_fastq(str(bad)))
+    bad.write_bytes(b"@r1\nACGT\nACGT\nACGT\nIIII\n")                         # never a '+' line
+    with pytest.raises(Exception, match="no '\\+' separator"):
+        list(iter_fastq(str(bad)))
+    with pytest.raises(Exception, match="cannot be split by byte ranges"):
+        with FastqReader(str(plain), byte_range=(0, len(text) // 2)) as rd:
+            list(rd.chunks(1000, 1 << 30))

@@ -1,5 +1,9 @@
 """`deepchopper predict reads.fq -b 12` end to end (the reference's default invocation: left-padded batches of 12, one 28 B/token
-`.pt` file per batch): wall time of the whole command, reads/s, MB of `.pt` written.   python tools/bench_cli_ref.py [reads]"""
+`.pt` file per batch): wall time of the whole command, reads/s, MB of `.pt` written -- on a nanopore-like length mix (what the
+command meets in practice: the pad tokens of a batch of 12 are 2.8x its real tokens) and, labelled as such, on fixed-length
+1 kb reads (no padding at all: the case in which the reference's batching costs nothing).
+
+    python tools/bench_cli_ref.py [reads]           # DC_SHARED_PREFIX=0 / DC_PREFIX_MODE=exact in the environment: the other forms"""
 import json
 import os
 import subprocess
@@ -9,24 +13,42 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
+
 from deepchopper_amd import synth
 from deepchopper_amd.weights import save_state_dict, synthetic_state_dict
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 tmp = tempfile.mkdtemp(prefix="dc_cli_")
-fq = os.path.join(tmp, "reads.fq")
-synth.write_fastq_fixed_fast(fq, n, 1000)
 ck = os.path.join(tmp, "ckpt")
 save_state_dict(synthetic_state_dict(0), os.path.join(ck, "model.safetensors"))
-out = os.path.join(tmp, "predictions")
-t0 = time.time()
-p = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "predict", fq, "-o", out, "-b", "12", "-m", ck], cwd=ROOT,
-                   capture_output=True, text=True)
-dt = time.time() - t0
-assert p.returncode == 0, p.stderr[-2000:]
-files = os.listdir(os.path.join(out, "0"))
-mb = sum(os.path.getsize(os.path.join(out, "0", f)) for f in files) / 1e6
-print(json.dumps({"command": "deepchopper predict reads.fq -b 12 (reference-compatible: .pt per batch of 12)", "reads": n, "bp": 1000,
-                  "seconds_whole_command": round(dt, 2), "reads_per_s": round(n / dt, 1), "pt_files": len(files), "pt_MB": round(mb, 1),
-                  "pt_MB_per_s": round(mb / dt, 1)}))
+
+
+def run(fq: str, what: str, lens) -> dict:
+    out = os.path.join(tmp, "predictions_" + what.split()[0])
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "predict", fq, "-o", out, "-b", "12", "-m", ck], cwd=ROOT,
+                       capture_output=True, text=True)
+    dt = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    files = os.listdir(os.path.join(out, "0"))
+    mb = sum(os.path.getsize(os.path.join(out, "0", f)) for f in files) / 1e6
+    padded = sum(int(lens[i: i + 12].max() + 1) * len(lens[i: i + 12]) for i in range(0, len(lens), 12))
+    subprocess.run(["rm", "-rf", out])
+    return {"command": "deepchopper predict reads.fq -b 12 (reference-compatible: .pt per batch of 12)", "input": what, "reads": len(lens),
+            "mean_bp": round(float(lens.mean()), 1), "padded_over_real_tokens": round(padded / float(lens.sum() + len(lens)), 3),
+            "seconds_whole_command": round(dt, 2), "reads_per_s": round(len(lens) / dt, 1), "Mbases_per_s": round(float(lens.sum()) / dt / 1e6, 2),
+            "pt_files": len(files), "pt_MB": round(mb, 1), "pt_MB_per_s": round(mb / dt, 1),
+            "shared_prefix": os.environ.get("DC_SHARED_PREFIX", "1") != "0", "prefix_mode": os.environ.get("DC_PREFIX_MODE", "linear")}
+
+
+fq = os.path.join(tmp, "nanopore_like.fq")
+heads, seqs, quals = synth.synth_nanopore_like(n, seed=77, gate=b"A")
+with open(fq, "wb") as fh:
+    fh.write(synth.fastq_text(heads, seqs, quals))
+print(json.dumps(run(fq, "nanopore-like lengths (log-normal, median 900 bp, 100 bp - 30 kb)", np.array([len(s) for s in seqs]))), flush=True)
+os.remove(fq)
+fq = os.path.join(tmp, "fixed_1kb.fq")
+synth.write_fastq_fixed_fast(fq, n, 1000)
+print(json.dumps(run(fq, "fixed-length 1 kb reads (no batch has any padding)", np.full(n, 1000))), flush=True)
 subprocess.run(["rm", "-rf", tmp])
