@@ -500,6 +500,7 @@ def main():
             "configs": configs or None,
             "per_rank_seconds": per_rank_s,
             "per_rank_cpuset": cpusets,
+            "cpu_budget": placed and {"cpus_worth_of_time": placed.get("cpu_budget"), "slices_cut_to_it": placed.get("capped_to_budget")},
             "cpu_baseline": cpu,
             "parity": f1,
             "fp16_overflow_events": fp16_overflow,

@@ -343,7 +343,8 @@ def _predict(args, argv: list[str]) -> int:
     logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
     report = {"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records, **_process_accounting(t_start)}
     if placed is not None:
-        report.update({"cpuset": placed["cpuset"], "numa_node": placed["numa_node"], "torch_threads": torch.get_num_threads()})
+        report.update({"cpuset": placed["cpuset"], "numa_node": placed["numa_node"], "torch_threads": torch.get_num_threads(),
+                       "cpu_budget": placed.get("cpu_budget"), "capped_to_budget": placed.get("capped_to_budget")})
     if pipe_src is not None:
         report.update({"pipe_read_cpu_s": round(pipe_src.cpu_s, 3), "pipe_bytes": pipe_src.bytes})
     if args.chop:

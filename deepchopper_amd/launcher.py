@@ -65,7 +65,8 @@ def rank_env(rank: int, world: int, port: int, share_gpu: bool = False, plan: di
     if plan is not None:
         sl = plan["ranks"][rank]
         env.update({"DC_CPUSET": placement.format_cpulist(sl["cpus"]), "DC_NUMA_NODE": str(sl["numa_node"]),
-                    "OMP_NUM_THREADS": str(len(sl["cpus"]))})
+                    "OMP_NUM_THREADS": str(len(sl["cpus"])),
+                    "DC_CPU_BUDGET": f"{plan.get('cpu_budget', 0)}:{'capped' if plan.get('capped') else 'fits'}"})
     return env
 
 

@@ -78,10 +78,11 @@ def cpu_quota(root: str = "/sys/fs/cgroup") -> float | None:
     return None
 
 
-def usable_cpu_count() -> int:
+def usable_cpu_count(cgroup_root: str | None = None, n_allowed: int | None = None) -> int:
     """How many CPUs a CPU-bound job here can really keep busy: the affinity mask capped by the cgroup quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    q = cpu_quota()
+    n = n_allowed if n_allowed is not None else (
+        len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    q = cpu_quota(cgroup_root or os.environ.get("DC_CGROUP_ROOT", "/sys/fs/cgroup"))  # (tests point this at a fake tree)
     return max(1, min(n, int(q + 0.5))) if q else n
 
 
@@ -141,18 +142,32 @@ def node_cpus(node: int, sysfs: str = "/sys") -> list[int] | None:
 
 
 def plan(world: int, *, local_devices: list[int] | None = None, sysfs: str | None = None, allowed: list[int] | None = None,
-         cores_per_rank: int | None = None, parent_cores: int | None = None) -> dict:
+         cores_per_rank: int | None = None, parent_cores: int | None = None, cgroup_root: str | None = None) -> dict:
     """CPU slices for the `world` workers of THIS node and for their parent.
 
     local_devices[r] = HIP device index of local rank r (default r; all 0 when ranks share one GPU).  Returns
-    {"ranks": [{"cpus": [...], "numa_node": n, "device": d}, ...], "parent": {"cpus": [...]} | None}.  Slices are disjoint
-    whenever the allowed CPUs suffice (world * 1 <= CPUs of the node); ranks of one node split that node's CPUs evenly when
-    `cores_per_rank` each do not fit.  Deterministic: every rank of an externally launched job computes the same plan."""
+    {"ranks": [{"cpus": [...], "numa_node": n, "device": d}, ...], "parent": {"cpus": [...]} | None, "cpu_budget": b,
+    "capped": bool}.  Slices are disjoint whenever the allowed CPUs suffice (world * 1 <= CPUs of the node); ranks of one node
+    split that node's CPUs evenly when `cores_per_rank` each do not fit.
+
+    The plan fits the CPU TIME the job really has: the affinity mask of a GPU box of the pool shows all 256 hardware threads
+    while its cgroup quota (`cpu.max`) is 16 CPUs' worth -- 8 x 5 + 6 = 46 pinned, busy threads would be throttled, not
+    helped.  `world * cores_per_rank + parent_cores` is capped at `usable_cpu_count()`: the per-rank slices shrink first
+    (never below one CPU, never overlapping), the parent keeps what is left of the budget (at least two CPUs while the
+    ranks can still have one each: it is the node's single inflater).  Deterministic: every rank of an externally
+    launched job computes the same plan."""
     cores_per_rank = int(os.environ.get("DC_CORES_PER_RANK", cores_per_rank or DEFAULT_CORES_PER_RANK))
     parent_cores = int(os.environ.get("DC_PARENT_CORES", parent_cores if parent_cores is not None else DEFAULT_PARENT_CORES))
     sysfs = sysfs or os.environ.get("DC_SYSFS_ROOT", "/sys")  # (tests point this at a fake tree)
     if allowed is None:
         allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    budget = usable_cpu_count(cgroup_root, len(allowed))
+    # (a job limited by its affinity mask alone is handled below: the ranks of a node split what the mask leaves of it)
+    capped = budget < len(allowed) and world * cores_per_rank + parent_cores > budget
+    if capped:
+        keep = min(parent_cores, 2) if budget >= world + 2 else 0
+        cores_per_rank = max(1, min(cores_per_rank, (budget - keep) // world))
+        parent_cores = min(parent_cores, max(budget - world * cores_per_rank, 0))
     allowed_set = set(allowed)
     local_devices = list(range(world)) if local_devices is None else list(local_devices)
     numa = gpu_numa_nodes(sysfs)
@@ -177,7 +192,7 @@ def plan(world: int, *, local_devices: list[int] | None = None, sysfs: str | Non
             taken.update(sl)
     left = [c for c in allowed if c not in taken]
     parent = {"cpus": left[:parent_cores]} if parent_cores > 0 and len(left) >= 1 else None
-    return {"ranks": ranks, "parent": parent}
+    return {"ranks": ranks, "parent": parent, "cpu_budget": budget, "capped": capped}
 
 
 def enabled() -> bool:
@@ -218,6 +233,9 @@ def _apply_for_this_rank(sysfs: str | None) -> dict | None:
     if given:
         info = apply(parse_cpulist(given))
         info["numa_node"] = int(os.environ.get("DC_NUMA_NODE", "-1"))
+        if os.environ.get("DC_CPU_BUDGET"):  # the launcher's plan: CPUs' worth of time the job has, and whether the slices were cut to it
+            info["cpu_budget"], _, cut = os.environ["DC_CPU_BUDGET"].partition(":")
+            info["cpu_budget"], info["capped_to_budget"] = int(info["cpu_budget"]), cut == "capped"
         return info
     lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if lws <= 1:
@@ -227,4 +245,5 @@ def _apply_for_this_rank(sysfs: str | None) -> dict | None:
     p = plan(lws, local_devices=[0] * lws if share else None, sysfs=sysfs)
     info = apply(p["ranks"][lr]["cpus"])
     info["numa_node"] = p["ranks"][lr]["numa_node"]
+    info["cpu_budget"], info["capped_to_budget"] = p["cpu_budget"], p["capped"]
     return info

@@ -11,6 +11,14 @@ from deepchopper_amd import launcher, placement
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _no_cgroup_quota(tmp_path, monkeypatch):
+    """The plan reads the cgroup CPU quota of the box it runs on; these tests bring their own (or none)."""
+    d = tmp_path / "cgroup_none"
+    d.mkdir()
+    monkeypatch.setenv("DC_CGROUP_ROOT", str(d))
+
+
 def make_sysfs(root, gpus_per_node=4, with_kfd=True, cpulists=("0-63,128-191", "64-127,192-255")):
     """KFD topology: two CPU nodes (simd_count 0) then the GPUs in enumeration order, each pointing at renderD<minor>, whose
     PCI device names its NUMA node -- deliberately NOT in PCI-address order, so that the mapping must come from the topology."""
@@ -145,3 +153,57 @@ def test_single_process_and_switched_off_runs_are_left_alone(monkeypatch):
     monkeypatch.setenv("DC_CPU_PLACEMENT", "0")
     assert placement.apply_for_this_rank() is None and launcher.cpu_plan(2) is None
     assert sorted(os.sched_getaffinity(0)) == before
+
+
+def test_plan_fits_the_cgroup_cpu_quota(tmp_path, monkeypatch):
+    """a GPU box of the pool shows 256 CPUs in the affinity mask and has a cgroup quota of 16 CPUs' worth
+    of time.  8 ranks x 5 + 6 = 46 pinned busy threads would be throttled: the plan shrinks the per-rank slices (never
+    below one CPU, never overlapping) before anything overlaps, the parent keeps what is left of the budget, every slice
+    stays on its GPU's NUMA node, and the cap is reported."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "DC_CORES_PER_RANK", "DC_PARENT_CORES"):
+        monkeypatch.delenv(var, raising=False)
+    numa_of = make_sysfs(tmp_path / "sys")
+    allowed = list(range(256))
+    node = {0: set(placement.parse_cpulist("0-63,128-191")), 1: set(placement.parse_cpulist("64-127,192-255"))}
+
+    def quota(tag, text):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "cpu.max").write_text(text)
+        return str(d)
+
+    def check(p, world, per_lo, per_hi, parent_n, budget):
+        assert p["cpu_budget"] == budget
+        seen = set()
+        for r, sl in enumerate(p["ranks"]):
+            assert per_lo <= len(sl["cpus"]) <= per_hi, (r, sl)
+            assert not (set(sl["cpus"]) & seen), "rank slices must be disjoint"
+            assert set(sl["cpus"]) <= node[numa_of[r]], "a rank stays on its GPU's NUMA node"
+            seen |= set(sl["cpus"])
+        par = set(p["parent"]["cpus"]) if p["parent"] else set()
+        assert len(par) == parent_n and not (par & seen)
+        if p["capped"]:
+            assert len(seen) + len(par) <= budget
+
+    # the pool's box: quota 16 of 256 -> 8 disjoint single-CPU slices, the parent's six inside the remaining eight
+    p = placement.plan(8, sysfs=str(tmp_path / "sys"), allowed=allowed, cgroup_root=quota("q16", "1600000 100000\n"))
+    assert p["capped"]
+    check(p, 8, 1, 1, 6, 16)
+    # quota 32: three CPUs per rank (8 x 3 = 24), parent 6, 30 <= 32
+    p = placement.plan(8, sysfs=str(tmp_path / "sys"), allowed=allowed, cgroup_root=quota("q32", "3200000 100000\n"))
+    assert p["capped"]
+    check(p, 8, 3, 3, 6, 32)
+    # quota 8 with 8 ranks: one CPU each, nothing left for a pinned parent
+    p = placement.plan(8, sysfs=str(tmp_path / "sys"), allowed=allowed, cgroup_root=quota("q8", "800000 100000\n"))
+    assert p["capped"] and p["parent"] is None
+    check(p, 8, 1, 1, 0, 8)
+    # no quota ("max") and a generous one: the full plan, not capped
+    for tag, text, budget in (("qmax", "max 100000\n", 256), ("q64", "6400000 100000\n", 64)):
+        p = placement.plan(8, sysfs=str(tmp_path / "sys"), allowed=allowed, cgroup_root=quota(tag, text))
+        assert not p["capped"]
+        check(p, 8, 5, 5, 6, budget)
+    # the worker's report carries the cap (self-launched: DC_CPU_BUDGET travels with DC_CPUSET)
+    p = placement.plan(8, sysfs=str(tmp_path / "sys"), allowed=allowed, cgroup_root=quota("q16b", "1600000 100000\n"))
+    env = launcher.rank_env(3, 8, 29500, plan=p)
+    assert env["DC_CPU_BUDGET"] == "16:capped" and env["OMP_NUM_THREADS"] == "1"
+    assert placement.usable_cpu_count(quota("q16c", "1600000 100000\n"), 256) == 16
