@@ -8,8 +8,9 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DC_IO_LIB") or os.path.join(_HERE, "lib", "libdeepchopper_io.so")
-# the C-ABI header: shipped inside an installed package (setup.py copies include/*.h there), in the repo next to the package
-HEADER_PATH = next((p for p in (os.path.join(_HERE, "include", "deepchopper_io.h"), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_io.h"))
+# the C-ABI header: in the repo next to the package (looked at first: a copy a local build left inside the package may be
+# stale), shipped inside an installed package (setup.py copies include/*.h there)
+HEADER_PATH = next((p for p in (os.path.join(os.path.dirname(_HERE), "include", "deepchopper_io.h"), os.path.join(_HERE, "include", "deepchopper_io.h"))
                     if os.path.exists(p)), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_io.h"))
 
 i64, vp = C.c_int64, C.c_void_p

@@ -13,8 +13,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DC_HIP_LIB") or os.path.join(_HERE, "lib", "libdeepchopper_hip.so")  # override: kernel A/B experiments
-# the C-ABI header: shipped inside an installed package (setup.py copies include/*.h there), in the repo next to the package
-HEADER_PATH = next((p for p in (os.path.join(_HERE, "include", "deepchopper_hip.h"), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h"))
+# the C-ABI header: in the repo next to the package (looked at first: a copy a local build left inside the package may be
+# stale), shipped inside an installed package (setup.py copies include/*.h there)
+HEADER_PATH = next((p for p in (os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h"), os.path.join(_HERE, "include", "deepchopper_hip.h"))
                     if os.path.exists(p)), os.path.join(os.path.dirname(_HERE), "include", "deepchopper_hip.h"))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "dc_model_set_gemm_mode": (C.c_int, [vp, i32]),
     "dc_model_set_mlp_fusion": (C.c_int, [vp, i32]),
     "dc_model_set_fft_threshold": (C.c_int, [vp, i32]),
+    "dc_model_set_fft_split": (C.c_int, [vp, i32]),
     "dc_model_overflow": (C.c_int, [vp, vp, C.POINTER(i32)]),
     "dc_model_set_overflow_target": (C.c_int, [vp, vp]),
     "dc_model_get_gemm_mode": (C.c_int, [vp, C.POINTER(i32)]),

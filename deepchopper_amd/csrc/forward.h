@@ -121,15 +121,29 @@ int gemm6_channel_block();  // output channels per block of the bf16x6 kernel (p
 int launch_filter(hipStream_t st, const FilterArgs& f);
 int launch_hyena2(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
 int launch_hyena3(hipStream_t st, const HyenaArgs& a, int n_groups, int max_P);
-// O(L log L) long convolution for long reads (hyena_fft.hip): 2^logm complex points per (read, channel), logm 11..14
-int fft_twiddle_count();                           // float2 entries of the twiddle table
+// O(L log L) long convolution for long reads (hyena_fft.hip), one workgroup per (read, channel).  Size classes, ordered by
+// capacity: `points` = M complex points of the transform = the longest sequence (tokens) the class takes.
+//   q == 1: one in-LDS radix-16 transform of 2^logn points
+//   q >= 2: split transform, q rows of 2^logn points (three radix-16 passes each; the zero half of the input and the unused
+//           half of the output are never computed; 3 x 4096 points for 8 193 .. 12 288 tokens)
+//   q == 0: the four-step 2^15-point form (two kernels, launch_hyena_fft15)
+// Classes 4 and 7 (direct 2^13 / 2^14: four passes) are the round 2-4 kernels for the sizes the split forms 3 and 6 now serve:
+// off by default, kept as the A/B reference (dc_model_set_fft_split(m, 0) / DC_FFT_SPLIT=0 restores the power-of-two classes).
+struct FftClassInfo {
+  int points, q, logn;
+};
+constexpr int kFftClasses = 9;
+constexpr int kFft15Class = kFftClasses - 1;
+inline constexpr FftClassInfo kFftClass[kFftClasses] = {{1024, 1, 10},  {2048, 1, 11},  {4096, 1, 12},  {8192, 2, 12}, {8192, 1, 13},
+                                                        {12288, 3, 12}, {16384, 4, 12}, {16384, 1, 14}, {32768, 0, 15}};
+int fft_twiddle_count();                           // float2 entries of the twiddle tables (one buffer)
 int launch_fft_twiddles(hipStream_t st, float* tw);
-int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t kf_stride, int kf_taps, int D,
-                            const float* tw, float* spec);  // spec: [D][2^logm + 1] float2
-int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,
+int launch_hyena_fft_filter(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
+                            const float* tw, float* spec);  // spec: [D][points + 1] float2
+int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int cls, const int32_t* reads, int n_reads, const float* tw,
                      const float* spec);
 // reads of 16 385 .. 32 769 tokens: 2^15 complex points as 16 x 2048 (two kernels, one scratch round trip of
-// hyena_fft15_scratch_bytes(n_reads, D)); the filter spectrum comes from launch_hyena_fft_filter(.., logm = 15, ..)
+// hyena_fft15_scratch_bytes(n_reads, D)); the filter spectrum comes from launch_hyena_fft_filter(.., kFft15Class, ..)
 int64_t hyena_fft15_scratch_bytes(int n_reads, int D);
 int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float* tw, const float* spec,
                        float* scratch);

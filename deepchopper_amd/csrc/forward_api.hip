@@ -37,7 +37,7 @@ struct LayerDev {
   unsigned short* kfp = nullptr;  // bf16 planes of the reversed filter, 8 shifted copies (hyena3)
   unsigned short* kfq = nullptr;  // fp16 planes (2) of the per-channel scaled filter
   float *kscale = nullptr, *kinv = nullptr;  // [D] power-of-two filter scale and its inverse
-  float* kspec[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // FFT long convolution: filter spectra [D][2^logm + 1] float2, logm 10..15
+  float* kspec[kFftClasses] = {};  // FFT long convolution: filter spectra [D][points + 1] float2 per size class (forward.h: kFftClass)
 };
 
 // linear shared prefix: positions of the zero stretch in front of the shared row's in the zc / Fc rows (>= the longest sequence
@@ -69,11 +69,12 @@ struct dc_model {
   int gemm_mode = 2;  // 0 = fp32 MFMA, 1 = bf16x6 (error-free 3-way bf16 split, fp32-equivalent), 2 = fp16x3 (2-way fp16 split)
   int64_t kf_taps = 0;
   float* fft_tw = nullptr;          // twiddle table of the FFT long convolution
-  bool kspec_valid[6] = {false, false, false, false, false, false};  // spectra match the materialised filters
+  bool kspec_valid[kFftClasses] = {};  // spectra match the materialised filters
+  uint32_t fft_class_mask = 0;      // size classes in use (bit per kFftClass entry; dc_model_set_fft_split / DC_FFT_CLASS_MASK)
   int fft_min_tokens = 2560;        // reads with more tokens take the FFT long convolution (dc_model_set_fft_threshold)
   // FFT buckets of the cached geometry: read lists by transform size
   int32_t* d_fft_reads = nullptr;
-  int fft_count[6] = {0, 0, 0, 0, 0, 0}, fft_offset[6] = {0, 0, 0, 0, 0, 0};  // logm 10..14 in LDS, 15 = the 16 x 2048 four-step form
+  int fft_count[kFftClasses] = {}, fft_offset[kFftClasses] = {};  // per size class; the last = the 16 x 2048 four-step form
   DevBuf fft_scratch;               // 2^15-point form: one HBM round trip between its two kernels
   int max_P_mfma = 0;
   int n_groups_long = 0;            // leading groups with reads above 1 024 tokens (16-block chunks); the rest fit one 32-block chunk
@@ -365,20 +366,30 @@ int ensure_filters(dc_model* m, hipStream_t st, int64_t taps_needed) {
   return DC_OK;
 }
 
-// Filter spectra of every layer for transforms of 2^logm complex points (built once per materialised filter).
-int ensure_fft_spectra(dc_model* m, hipStream_t st, int logm) {
-  const int b = logm - 10;
-  DC_REQUIRE(b >= 0 && b < 6, "FFT size out of range");
+// Size classes of the FFT long convolution in use: the split forms (default) or the power-of-two transforms of rounds 2-4.
+uint32_t fft_mask_for(bool split) {
+  uint32_t mask = 0;
+  for (int k = 0; k < kFftClasses; ++k) {
+    const FftClassInfo& ci = kFftClass[k];
+    const bool shadowed = ci.q == 1 && ci.points >= 8192;  // direct 2^13 / 2^14: served by the split forms of the same size
+    if (split ? !shadowed : ci.q <= 1) mask |= 1u << k;
+  }
+  return mask;
+}
+
+// Filter spectra of every layer for the transforms of size class b (built once per materialised filter).
+int ensure_fft_spectra(dc_model* m, hipStream_t st, int b) {
+  DC_REQUIRE(b >= 0 && b < kFftClasses, "FFT size class out of range");
   if (!m->fft_tw) {
     DC_HIP_CHECK(hipMalloc((void**)&m->fft_tw, (size_t)fft_twiddle_count() * 2 * sizeof(float)));
     int rc = launch_fft_twiddles(st, m->fft_tw);
     if (rc) return rc;
   }
   if (m->kspec_valid[b]) return DC_OK;
-  const size_t bytes = (size_t)m->cfg.d_model * (((size_t)1 << logm) + 1) * 2 * sizeof(float);
+  const size_t bytes = (size_t)m->cfg.d_model * ((size_t)kFftClass[b].points + 1) * 2 * sizeof(float);
   for (auto& L : m->layers) {
     if (!L.kspec[b]) DC_HIP_CHECK(hipMalloc((void**)&L.kspec[b], bytes));
-    int rc = launch_hyena_fft_filter(st, logm, L.kf, m->kf_taps, (int)m->kf_taps, m->cfg.d_model, m->fft_tw, L.kspec[b]);
+    int rc = launch_hyena_fft_filter(st, b, L.kf, m->kf_taps, (int)m->kf_taps, m->cfg.d_model, m->fft_tw, L.kspec[b]);
     if (rc) return rc;
   }
   m->kspec_valid[b] = true;
@@ -476,20 +487,21 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   key.push_back((int32_t)(row_stride & 0x7fffffff));
   key.push_back((int32_t)(row_stride >> 31));
   key.push_back(m->fft_min_tokens);
+  key.push_back((int32_t)m->fft_class_mask);
   key.push_back(h_npad ? 1 + pad_id + 1024 * m->prefix_mode : 0);
   key.insert(key.end(), h_first, h_first + n_reads);
   key.insert(key.end(), h_ntok, h_ntok + n_reads);
   if (h_npad) key.insert(key.end(), h_npad, h_npad + n_reads);
   if (key == m->h_geom && m->Tp > 0) return DC_OK;
 
-  // long-convolution class of a sequence of nt positions: 0 = block-Toeplitz MFMA, 1 + b = FFT of 2^(10 + b) complex points.
-  // Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by transform size: up to 2^14
-  // tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form.
+  // long-convolution class of a sequence of nt positions: 0 = block-Toeplitz MFMA, 1 + b = FFT size class b (forward.h:
+  // kFftClass, ordered by capacity).  Long reads (more than fft_min_tokens tokens) take the FFT long convolution, bucketed by
+  // transform size: up to 16 384 tokens one in-LDS transform, up to 2^15 + 1 (the model's whole context) the four-step form.
   auto conv_class = [&](int nt) -> int {
     if (nt > m->fft_min_tokens && nt <= (1 << 15) + 1) {
-      int logm = 10;
-      while ((1 << logm) < nt && logm < 15) ++logm;  // 2^15 + 1 tokens still fit the 2^15 form (one tap added by hand)
-      return 1 + logm - 10;
+      for (int b = 0; b < kFftClasses; ++b)
+        if ((m->fft_class_mask >> b & 1u) && nt <= kFftClass[b].points) return 1 + b;
+      return 1 + kFft15Class;  // 2^15 + 1 tokens still fit the 2^15 form (one tap added by hand)
     }
     return 0;
   };
@@ -506,7 +518,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   // read's sequence starts 4 positions in front of its own slots (the short filter's halo) and its long convolution
   // costs what it costs without padding; its class follows its own length.
   const bool linear = h_npad && m->prefix_mode == 2;
-  int pad_len[7] = {0, 0, 0, 0, 0, 0, 0};
+  int pad_len[kFftClasses + 1] = {};
   std::vector<int32_t> pv(n_reads, 0), t0(n_reads, 0);  // pv: positions of a read's sequence the shared row holds; t0: position of the shared row the read's sequence starts at
   int n_fill = 0;
   for (int r = 0; r < n_reads; ++r) {
@@ -526,10 +538,10 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
       pad_len[k] = std::max(pad_len[k], (int)pv[r]);
     }
   }
-  int pad_unit[7], n_units = n_reads;
+  int pad_unit[kFftClasses + 1], n_units = n_reads;
   int64_t padlog_len = 0;
-  int32_t padlog_off[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int k = 0; k < 7; ++k) {
+  int32_t padlog_off[kFftClasses + 1] = {};
+  for (int k = 0; k < kFftClasses + 1; ++k) {
     pad_unit[k] = -1;
     if (pad_len[k] > 0) {
       pad_unit[k] = n_units++;
@@ -592,7 +604,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
   // (linear form: the shared row runs in a launch of its own in front of the reads' -- they need its z and F -- as a group / a
   //  read list of one behind the others')
   const int lin_pad = linear && sp ? pad_unit[0] : -1;
-  std::vector<int32_t> fft_lists[6], mfma_order;
+  std::vector<int32_t> fft_lists[kFftClasses], mfma_order;
   for (int j = 0; j < n_units; ++j) {
     const int u = order[j];
     if (u == lin_pad) continue;
@@ -609,7 +621,7 @@ int setup_geometry(dc_model* m, hipStream_t st, int n_reads, int64_t row_stride,
     maxP_mfma = std::max(maxP_mfma, nblk[mfma_order[j]]);
   }
   std::vector<int32_t> fft_reads;
-  for (int b = 0; b < 6; ++b) {
+  for (int b = 0; b < kFftClasses; ++b) {
     m->fft_offset[b] = (int)fft_reads.size();
     m->fft_count[b] = (int)fft_lists[b].size();
     fft_reads.insert(fft_reads.end(), fft_lists[b].begin(), fft_lists[b].end());
@@ -806,17 +818,17 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
   // taps: materialising all M makes it -- and with it the last bits of the result -- independent of what the handle saw before)
   int64_t taps_needed = (int64_t)m->max_P * 32;
   const int pad_fft = m->linear_prefix && m->lin_pad_cls > 0 ? m->lin_pad_cls - 1 : -1;  // the linear form's shared row on an FFT class
-  for (int b = 0; b < 6; ++b)
-    if (m->fft_count[b] || b == pad_fft) taps_needed = std::max<int64_t>(taps_needed, (int64_t)1 << (10 + b));
+  for (int b = 0; b < kFftClasses; ++b)
+    if (m->fft_count[b] || b == pad_fft) taps_needed = std::max<int64_t>(taps_needed, (int64_t)kFftClass[b].points);
   if ((rc = ensure_filters(m, st, taps_needed))) return rc;
-  for (int b = 0; b < 6; ++b)
-    if ((m->fft_count[b] || b == pad_fft) && (rc = ensure_fft_spectra(m, st, 10 + b))) return rc;
+  for (int b = 0; b < kFftClasses; ++b)
+    if ((m->fft_count[b] || b == pad_fft) && (rc = ensure_fft_spectra(m, st, b))) return rc;
   // reads per launch pair of the 2^15 form.  The scratch is D x 2^15 complex = 64 MiB per read and stays with the handle, so
   // the batch is what bounds a handle's footprint: 4 reads = 256 MiB at most (16 would hold 1 GiB for good, per handle --
   // lanes, or ranks sharing a GPU), and a launch of 4 reads is already 8 x 4 x 256 = 8 192 workgroups
   constexpr int kFft15Batch = 4;
-  if (m->fft_count[5] || pad_fft == 5) {
-    const size_t need = (size_t)hyena_fft15_scratch_bytes(std::max(1, std::min(m->fft_count[5], kFft15Batch)), c.d_model);
+  if (m->fft_count[kFft15Class] || pad_fft == kFft15Class) {
+    const size_t need = (size_t)hyena_fft15_scratch_bytes(std::max(1, std::min(m->fft_count[kFft15Class], kFft15Batch)), c.d_model);
     if (m->fft_scratch.bytes < need) {
       DC_HIP_CHECK(hipStreamSynchronize(st));  // earlier launches may still read the buffer about to be freed
       // every (k1, b) of a (read, channel) is stored by the first kernel before the second one loads it: no zero fill
@@ -923,10 +935,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
           ap.grp_reads = a.grp_reads + (size_t)m->n_groups * 32;
           ap.grp_P = a.grp_P + m->n_groups;
           rc = hy == 2 ? launch_hyena2(st, ap, 1, m->lin_pad_P) : launch_hyena3(st, ap, 1, m->lin_pad_P);
-        } else if (k <= 5) {
-          rc = launch_hyena_fft(st, ap, 10 + k - 1, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[k - 1]);
+        } else if (k - 1 < kFft15Class) {
+          rc = launch_hyena_fft(st, ap, k - 1, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[k - 1]);
         } else {
-          rc = launch_hyena_fft15(st, ap, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[5], (float*)m->fft_scratch.p);
+          rc = launch_hyena_fft15(st, ap, m->d_fft_reads + m->lin_pad_fft_index, 1, m->fft_tw, L.kspec[kFft15Class],
+                                  (float*)m->fft_scratch.p);
         }
         if (rc) return rc;
         if ((rc = launch_pad_row_finish(st, u, a.tok ? a.tab : nullptr, m->pad_id, D, Tp, m->lin_pad_toff, m->lin_pad_len, L.sw, L.sb, y,
@@ -954,16 +967,17 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
         if (rc) return rc;
       }
       // long reads: O(L log L) FFT convolution, one launch per transform size present in the batch
-      for (int b = 0; b < 5; ++b) {
+      for (int b = 0; b < kFft15Class; ++b) {
         if (m->fft_count[b] == 0) continue;
         ProfScope pf(m, st, "hyena_fft");
-        if ((rc = launch_hyena_fft(st, a, 10 + b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
+        if ((rc = launch_hyena_fft(st, a, b, m->d_fft_reads + m->fft_offset[b], m->fft_count[b], m->fft_tw, L.kspec[b])))
           return rc;
       }
-      for (int r0 = 0; r0 < m->fft_count[5]; r0 += kFft15Batch) {  // 16 385 .. 32 769 tokens: 16 x 2048 four-step form
+      for (int r0 = 0; r0 < m->fft_count[kFft15Class]; r0 += kFft15Batch) {  // 16 385 .. 32 769 tokens: 16 x 2048 four-step form
         ProfScope pf(m, st, "hyena_fft15");
-        if ((rc = launch_hyena_fft15(st, a, m->d_fft_reads + m->fft_offset[5] + r0, std::min(kFft15Batch, m->fft_count[5] - r0),
-                                     m->fft_tw, L.kspec[5], (float*)m->fft_scratch.p)))
+        if ((rc = launch_hyena_fft15(st, a, m->d_fft_reads + m->fft_offset[kFft15Class] + r0,
+                                     std::min(kFft15Batch, m->fft_count[kFft15Class] - r0), m->fft_tw, L.kspec[kFft15Class],
+                                     (float*)m->fft_scratch.p)))
           return rc;
       }
     }
@@ -1071,6 +1085,12 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
   if (const char* e = getenv("DC_GEMM_MODE"))
     m->gemm_mode = (strcmp(e, "f32") == 0 || strcmp(e, "0") == 0) ? 0 : ((strcmp(e, "fp16x3") == 0 || strcmp(e, "2") == 0) ? 2 : 1);
   if (const char* e = getenv("DC_FFT_MIN")) m->fft_min_tokens = std::max(256, atoi(e));
+  {
+    const char* e = getenv("DC_FFT_SPLIT");
+    m->fft_class_mask = fft_mask_for(!(e && atoi(e) == 0));
+    // experiments: an explicit set of size classes (bit k = kFftClass[k]); the four-step class is always available
+    if (const char* cm = getenv("DC_FFT_CLASS_MASK")) m->fft_class_mask = ((uint32_t)strtoul(cm, nullptr, 0) | 1u << kFft15Class) & ((1u << kFftClasses) - 1);
+  }
   if (const char* e = getenv("DC_PREFIX_MODE")) m->prefix_mode = (strcmp(e, "linear") == 0 || strcmp(e, "2") == 0) ? 2 : 1;
   DC_HIP_CHECK(hipGetDevice(&m->device));
   DC_HIP_CHECK(hipEventCreateWithFlags(&m->staging_done, hipEventDisableTiming));
@@ -1334,6 +1354,12 @@ extern "C" int dc_model_overflow(dc_model* m, void* stream, int32_t* count) {
   DC_HIP_CHECK(hipStreamSynchronize(st));
   if (v) DC_HIP_CHECK(hipMemsetAsync(m->d_overflow, 0, sizeof(int), st));
   *count = v;
+  return DC_OK;
+}
+
+extern "C" int dc_model_set_fft_split(dc_model* m, int32_t on) {
+  DC_REQUIRE(m, "null model");
+  m->fft_class_mask = fft_mask_for(on != 0);
   return DC_OK;
 }
 

@@ -24,12 +24,16 @@ namespace dc {
 namespace {
 
 constexpr int FFT_TW_N = 65536;  // twiddle table: exp(-2 pi i n / 65536) (the 2^15-point form needs the 2^16-th roots)
+// The split transform of 3 x 4096 points needs roots the 2^16 table does not hold: the 24 576-th roots (W_2M for M = 12 288)
+// stand behind it in the same buffer.
+constexpr int FFT_TW3_N = 24576;
+constexpr int FFT_TW3_OFF = FFT_TW_N, FFT_TW_TOTAL = FFT_TW_N + FFT_TW3_N;
 
-__global__ __launch_bounds__(256) void fft_twiddle_kernel(float2* __restrict__ tw) {
+__global__ __launch_bounds__(256) void fft_twiddle_kernel(float2* __restrict__ tw, int count) {  // tw[n] = exp(-2 pi i n / count)
   const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= FFT_TW_N) return;
+  if (n >= count) return;
   double s, c;
-  sincospi(-2.0 * (double)n / (double)FFT_TW_N, &s, &c);
+  sincospi(-2.0 * (double)n / (double)count, &s, &c);
   tw[n] = make_float2((float)c, (float)s);
 }
 
@@ -549,6 +553,370 @@ struct GateSrc {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Split transforms (round 5): M = Q x N2 complex points, N2 = 2^LOGN, Q = 2, 3, 4 (and Q = 1: the same kernel around one
+// row) -- one outer step of the four-step factorisation around the in-LDS radix-16 code, all of it in LDS (Q rows of N2
+// points, one group of N2 / 16 threads each):
+//   forward   m = n2 + N2 n1:   b_k1[n2] = W_M^(n2 k1) sum_n1 c[n2 + N2 n1] W_Q^(n1 k1);   C[k1 + Q k2] = FFT_N2(b_k1)[k2]
+//   product   pairs k <-> M - k of the packed real transform; C[k] lives in row k mod Q at index k div Q
+//   inverse   R_k1 = FFT_N2(row k1);   r[b + N2 a] = sum_k1 R_k1[b] W_M^(k1 b) W_Q^(k1 a)
+// What it buys over one 2^LOGM transform of the next power of two:
+//   * the packed input fills at most HALF of the M points (2M real samples >= 2L), so the outer forward step has
+//     ceil(Q / 2) terms instead of Q (Q = 2: none -- row 1 is row 0 times a twiddle), and only the outputs r[n], n < M / 2,
+//     are wanted, so the outer inverse step is evaluated for a < ceil(Q / 2) only: the zero half of the first pass and the
+//     discarded half of the last one are never computed;
+//   * N2 = 4096 transforms in THREE radix-16 passes where 2^13 / 2^14 points take four;
+//   * M need not be a power of two: 3 x 4096 points serve reads of 8 193 .. 12 288 tokens that paid for 16 384.
+// And the kernel around the transforms is organised by memory round trips, which is what a workgroup's life consisted of
+// (two workgroups per CU, 8 dependent global round trips of ~3 us each in the round-2 form): the channel's x1 | v rows are
+// staged in the transform's own LDS with 16-byte loads, all in flight at once; the spectrum loads of the product phase and
+// the output gate's loads are each one batch; the twiddles of the outer steps and of the product phase are one table look-up
+// per thread times compile-time roots of unity.  Measured on the config-4 length mix (profiles/r05b_*): 2^13 class 2.16 ->
+// 0.70 + (the 6 144-point class, dropped: 1.04) ms per launch; FFT stage -25 %.  Size classes that were built and measured
+// and did NOT pay -- 3 x 1024, 3 x 2048, 5 x 2048 points: fewer points, but 3 / 6 / 10 waves per workgroup fill a CU worse
+// than 8 / 12 / 16 -- are not instantiated (profiles/r05b_fft_class_sweep.jsonl).
+// W_M / W_2M come from `twq` (W_2M^n = twq[n * qstep]: the 2^16 table for Q = 1, 2, 4; the 24 576-th roots for Q = 3), the
+// rows' own twiddles from the 2^16 table as before.
+// ---------------------------------------------------------------------------------------------------
+template <int LOGN, int Q>
+struct SplitGeo {
+  static constexpr int N2 = 1 << LOGN, M = Q * N2, TG = N2 / 16, T = Q * TG;
+  static constexpr int NZ = (Q + 1) / 2;      // blocks of N2 points that can hold input / wanted output (points < M / 2)
+  static constexpr int NJ = (16 + Q - 1) / Q;  // "one n2 per thread" iterations that cover a row (T = Q N2 / 16 threads)
+  // Padded row + an offset that spreads the Q rows over the LDS banks for the product phase (lane -> row k mod Q)
+  static constexpr int ROW = N2 + N2 / 16 + (Q == 2 ? 16 : Q == 3 ? 11 : Q == 4 ? 8 : 0);
+  static constexpr size_t smem = (size_t)Q * ROW * sizeof(float2) + 64 * sizeof(float);
+};
+
+// x * exp(-2 pi i e / Q); e is a compile-time constant wherever this is called (fully unrolled loops)
+template <int Q>
+__device__ __forceinline__ v2f mul_wq(v2f x, int e) {
+  e %= Q;
+  if (e == 0) return x;
+  if (Q % 2 == 0 && e == Q / 2) return -x;
+  if (Q % 4 == 0 && e == Q / 4) return v2f{x.y, -x.x};       // * (-i)
+  if (Q % 4 == 0 && e == 3 * Q / 4) return v2f{-x.y, x.x};   // * (+i)
+  float c = 1.f, s = 0.f;
+  if (Q == 3) {
+    c = -0.5f;
+    s = e == 1 ? -0.86602540378443865f : 0.86602540378443865f;
+  }
+  return vcmul(x, v2f{c, s});
+}
+
+// LDS slot of bin k of the split layout
+template <int LOGN, int Q>
+__device__ __forceinline__ int split_at(int k) {
+  const int q = k / Q;
+  return (k - q * Q) * SplitGeo<LOGN, Q>::ROW + pad16(q);
+}
+
+// Outer forward step for one n2: z[n1] = c[n2 + N2 n1] (n1 < NZ) -> the Q row entries b_k1[n2]; wf[k1] = W_M^(n2 k1), k1 >= 1
+template <int LOGN, int Q>
+__device__ __forceinline__ void split_forward_store(float2* __restrict__ s, int n2, const v2f (&z)[SplitGeo<LOGN, Q>::NZ],
+                                                    const float2 (&wf)[Q]) {
+  using G = SplitGeo<LOGN, Q>;
+  float2* const col = s + pad16(n2);
+#pragma unroll
+  for (int k1 = 0; k1 < Q; ++k1) {
+    v2f acc = z[0];
+#pragma unroll
+    for (int n1 = 1; n1 < G::NZ; ++n1) acc += mul_wq<Q>(z[n1], n1 * k1);
+    col[k1 * G::ROW] = F(k1 == 0 ? acc : vcmul(acc, V(wf[k1])));
+  }
+}
+
+template <int LOGN, int Q>
+__global__ __launch_bounds__(Q * (1 << LOGN) / 16) void hyena_fftq_filter_kernel(const float* __restrict__ kf, int64_t kf_stride,
+                                                                                  int kf_taps, const float2* __restrict__ tw,
+                                                                                  const float2* __restrict__ twq, int qstep,
+                                                                                  float2* __restrict__ spec) {
+  using G = SplitGeo<LOGN, Q>;
+  constexpr int N2 = G::N2, M = G::M, T = G::T, TG = G::TG, NZ = G::NZ, NJ = G::NJ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_rawq[];
+  float2* s = reinterpret_cast<float2*>(s_rawq);
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float* k = kf + (int64_t)c * kf_stride;
+  const int taps = kf_taps < M ? kf_taps : M;
+#pragma unroll 1
+  for (int j = 0; j < NJ; ++j) {
+    const int n2 = tid + j * T;
+    if (n2 >= N2) break;
+    v2f z[NZ];
+    float2 wf[Q];
+#pragma unroll
+    for (int n1 = 0; n1 < NZ; ++n1) {
+      const int t = 2 * (n2 + N2 * n1);
+      z[n1] = v2f{t < taps ? k[t] : 0.f, t + 1 < taps ? k[t + 1] : 0.f};
+    }
+#pragma unroll
+    for (int k1 = 1; k1 < Q; ++k1) wf[k1] = twq[2 * n2 * k1 * qstep];
+    split_forward_store<LOGN, Q>(s, n2, z, wf);
+  }
+  __syncthreads();
+  const int grp = tid / TG;
+  fft_lds<LOGN>(s + grp * G::ROW, tw, tid - grp * TG);
+  float2* out = spec + (int64_t)c * (M + 1);
+  for (int kk = tid; kk <= M / 2; kk += T) {
+    const float2 ck = s[split_at<LOGN, Q>(kk)], cmk = s[split_at<LOGN, Q>(kk ? M - kk : 0)];
+    float2 zk, zmk;
+    unpack_pair<0>(ck, cmk, twq[kk * qstep], zk, zmk);
+    if (kk == 0) {
+      out[0] = make_float2(ck.x + ck.y, 0.f);
+      out[M] = make_float2(ck.x - ck.y, 0.f);
+    } else {
+      out[kk] = zk;
+      out[M - kk] = zmk;
+    }
+  }
+}
+
+template <int LOGN, int Q, bool TAB, int SP>
+__global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
+                                                                          const float2* __restrict__ tw,
+                                                                          const float2* __restrict__ twq, int qstep,
+                                                                          const float2* __restrict__ spec) {
+  using G = SplitGeo<LOGN, Q>;
+  constexpr int N2 = G::N2, M = G::M, T = G::T, TG = G::TG, NZ = G::NZ, ROW = G::ROW;
+  // "one n2 per thread" iterations.  Q == 1 (one row, no outer step): input and wanted output fill the first half of the row
+  constexpr int NJ = Q == 1 ? 8 : G::NJ;
+  constexpr bool DL = SP == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_rawq[];
+  float2* s = reinterpret_cast<float2*>(s_rawq);
+  float* s_tab = reinterpret_cast<float*>(s + Q * ROW);
+  const int r = reads[blockIdx.x], c = blockIdx.y, tid = threadIdx.x;
+  if (TAB) {
+    if (tid < 3 * 17) {
+      const int k3 = tid / 17, id = tid - 17 * k3;
+      s_tab[tid] = id < a.vocab && id < 16 ? a.tab[(int64_t)id * 3 * a.D + k3 * a.D + c] : 0.f;
+    }
+  }
+  using Gate = GateSrc<TAB, SP>;
+  using Raw = typename Gate::Raw;
+  Gate g;
+  g.init(a, r, c, s_tab);
+  const int L = g.L, t_last = g.t_last;
+
+  // W_M^(tid k1): the outer steps' twiddle of n2 = tid + j T is this times W_16^(j k1) (T = M / 16), a compile-time constant
+  float2 wb[Q];
+#pragma unroll
+  for (int k1 = 1; k1 < Q; ++k1) wb[k1] = twq[2 * tid * k1 * qstep];
+
+  // ---- stage the channel's x1 | v rows (TAB: the token ids) in the transform's LDS: 16-byte loads, all of them in flight at
+  //      once -- one memory round trip for the whole gated input (the per-iteration loads of the first version were 3 of 8
+  //      dependent round trips of a workgroup's life)
+  float* const sf = reinterpret_cast<float*>(s);          // x1[t] at sf[t], v[t] at sf[M + t]
+  unsigned char* const sb = reinterpret_cast<unsigned char*>(s);  // TAB: id of position t at sb[t]
+  constexpr int NS = (M / 4 + T - 1) / T;  // groups of 4 positions per thread
+  static_assert(NS == 4, "staging is written out for four groups per thread");
+  float2 zsub[NJ][NZ];
+  {
+    // (four named groups, not an array: hipcc kept an indexed array of these in scratch memory)
+    float4 a1_0, a1_1, a1_2, a1_3, av_0, av_1, av_2, av_3;
+    uint32_t aw_0 = 0, aw_1 = 0, aw_2 = 0, aw_3 = 0;
+#define DC_STAGE_LOAD(i)                                                  \
+  {                                                                       \
+    const int t4 = 4 * (tid + i * T);                                     \
+    const int sl = g.slot(t4 < L ? t4 : 0);                               \
+    if (TAB) {                                                            \
+      aw_##i = *reinterpret_cast<const uint32_t*>(g.tok + sl);            \
+    } else {                                                              \
+      a1_##i = *reinterpret_cast<const float4*>(g.ux1 + sl);              \
+      av_##i = *reinterpret_cast<const float4*>(g.uv + sl);               \
+    }                                                                     \
+  }
+    DC_STAGE_LOAD(0) DC_STAGE_LOAD(1) DC_STAGE_LOAD(2) DC_STAGE_LOAD(3)
+#undef DC_STAGE_LOAD
+    if (DL) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int n1 = 0; n1 < NZ; ++n1) {
+          const int t = 2 * (tid + j * T + N2 * n1);
+          zsub[j][n1] = *reinterpret_cast<const float2*>(g.zcrow + (t < t_last ? t : t_last));
+        }
+      }
+    }
+#define DC_STAGE_STORE(i)                                                 \
+  {                                                                       \
+    const int t4 = 4 * (tid + i * T);                                     \
+    if (t4 < L) {                                                         \
+      if (TAB) {                                                          \
+        *reinterpret_cast<uint32_t*>(sb + t4) = aw_##i;                   \
+      } else {                                                            \
+        *reinterpret_cast<float4*>(sf + t4) = a1_##i;                     \
+        *reinterpret_cast<float4*>(sf + M + t4) = av_##i;                 \
+      }                                                                   \
+    }                                                                     \
+  }
+    DC_STAGE_STORE(0) DC_STAGE_STORE(1) DC_STAGE_STORE(2) DC_STAGE_STORE(3)
+#undef DC_STAGE_STORE
+  }
+  __syncthreads();
+
+  // ---- gated input pairs of this thread, from the staged rows ----
+  v2f z[NJ][NZ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n2 = tid + j * T;
+#pragma unroll
+    for (int n1 = 0; n1 < NZ; ++n1) {
+      const int t = 2 * (n2 + N2 * n1);
+      v2f zz = v2f{0.f, 0.f};
+      if (t < L && (Q == 1 || (16 % Q) == 0 || n2 < N2)) {
+        Raw r1, rv;
+        if (TAB) {
+          const uint32_t lo16 = t >= 2 ? *reinterpret_cast<const unsigned short*>(sb + t - 2) : 0xFFFFu;
+          uint32_t ids = lo16 | ((uint32_t)*reinterpret_cast<const unsigned short*>(sb + t) << 16);
+          if (t + 1 >= L) ids |= 0xFF000000u;
+          r1.lo = make_float2(__builtin_bit_cast(float, ids), 0.f);
+          r1.hi = make_float2(0.f, 0.f);
+          rv = r1;
+        } else {
+          const int tl = t >= 2 ? t - 2 : 0;
+          r1.lo = *reinterpret_cast<const float2*>(sf + tl);
+          r1.hi = *reinterpret_cast<const float2*>(sf + t);
+          rv.lo = *reinterpret_cast<const float2*>(sf + M + tl);
+          rv.hi = *reinterpret_cast<const float2*>(sf + M + t);
+          if (t < 2) r1.lo = rv.lo = make_float2(0.f, 0.f);
+        }
+        zz = g.sc_eval(1, r1) * g.sc_eval(2, rv);
+        if (DL) zz = t < g.pv ? v2f{0.f, 0.f} : zz - V(zsub[j][n1]);
+        if (t + 1 >= L) zz.y = 0.f;
+      }
+      z[j][n1] = zz;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (all 4 NJ NZ LDS reads hoisted to the front cost ~90 VGPRs)
+  }
+  __syncthreads();
+
+  // ---- outer forward step -> rows ----
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n2 = tid + j * T;
+    if (Q == 1) {
+      s[pad16(n2)] = F(z[j][0]);
+      s[pad16(n2 + N2 / 2)] = make_float2(0.f, 0.f);
+    } else if ((16 % Q) == 0 || n2 < N2) {
+      float2 wf[Q];
+#pragma unroll
+      for (int k1 = 1; k1 < Q; ++k1) {
+        const int e = (j * k1) & 15;
+        wf[k1] = e == 0 ? wb[k1] : cmul(wb[k1], unit_root(e, 16));
+      }
+      split_forward_store<LOGN, Q>(s, n2, z[j], wf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  const int grp = tid / TG;
+  fft_lds<LOGN>(s + grp * ROW, tw, tid - grp * TG);
+
+  // ---- spectrum product and repacking for the inverse transform (stored conjugated: IFFT = conj . FFT . conj) ----
+  const float2* K = spec + (int64_t)c * (M + 1);
+  auto product = [&](int kk, float2 kf_, float2 kb_, float2 wk_) {  // kf = K[kk], kb = K[M - kk], wk = W_2M^kk
+    float2* const pk = s + split_at<LOGN, Q>(kk);
+    const v2f ck = V(*pk);
+    const v2f kf = V(kf_), kb = V(kb_), wk = V(wk_);
+    if (kk == 0) {
+      const float y0 = (ck.x + ck.y) * kf.x;   // Y[0]  (real)
+      const float ym = (ck.x - ck.y) * kb.x;   // Y[M]  (real)
+      *pk = make_float2(0.5f * (y0 + ym), -0.5f * (y0 - ym));
+      return;
+    }
+    float2* const pmk = s + split_at<LOGN, Q>(M - kk);
+    const v2f cmk = V(*pmk);
+    const v2f half = 0.5f;
+    const v2f bc = vconj(cmk);
+    const v2f e = half * (ck + bc), d = half * (ck - bc);
+    const v2f wo = vcmul(wk, v2f{d.y, -d.x});
+    const v2f zk = e + wo, zmk = vconj(e - wo);
+    const v2f yk = vcmul(zk, kf), ymk = vcmul(zmk, kb);
+    const v2f bq = vconj(ymk);
+    const v2f ye = half * (yk + bq), d2 = half * (yk - bq);
+    const v2f yo = vcmul(vconj(wk), d2);
+    const v2f cp = ye + v2f{-yo.y, yo.x};
+    const v2f cq = vconj(ye) + v2f{yo.y, yo.x};
+    *pk = F(vconj(cp));
+    if (2 * kk != M) *pmk = F(vconj(cq));
+  };
+  {
+    // kk = tid + j T, j < 8 (kk < 8 T = M / 2: every pair (kk, M - kk) belongs to exactly one thread).  All sixteen spectrum
+    // loads in flight at once; W_2M^kk = W_2M^tid W_32^j (T = M / 16) needs one table look-up instead of eight gathers.
+    float2 kf[8], kb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = tid + j * T;
+      kf[j] = K[kk];
+      kb[j] = K[M - kk];
+    }
+    const float2 wk0 = twq[tid * qstep];
+    const float2 km = K[M / 2], wm = twq[(M / 2) * qstep];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                                0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
+      const float2 wk = j == 0 ? wk0 : cmul(wk0, make_float2(C32[j], -C32[8 - j]));  // exp(-2 pi i j / 32)
+      product(tid + j * T, kf[j], kb[j], wk);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid == 0) product(M / 2, km, km, wm);  // the self-paired middle bin
+  }
+  __syncthreads();
+
+  fft_lds<LOGN>(s + grp * ROW, tw, tid - grp * TG);
+  // (opaque copies: left alone, hipcc keeps the NJ (Q - 1) products wb W_16^(j k1) of the forward step alive -- spilled --
+  //  across both transforms to reuse them below; recomputing them is a dozen packed multiplies)
+#pragma unroll
+  for (int k1 = 1; k1 < Q; ++k1) asm volatile("" : "+v"(wb[k1].x), "+v"(wb[k1].y));
+
+  // the output gate's inputs: every load of the output phase in flight at once -- one round trip
+  Raw r0[NJ][NZ];
+  float2 fadd[NJ][NZ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int aa = 0; aa < NZ; ++aa) {
+      const int t = 2 * (tid + j * T + N2 * aa);
+      r0[j][aa] = g.raw_load(g.ux0, t);
+      if (DL) fadd[j][aa] = *reinterpret_cast<const float2*>(g.fcrow + (t < t_last ? t : t_last));
+    }
+  }
+
+  // ---- outer inverse step for the wanted half, output gate: conv[2n] = Re r[n] / M, conv[2n+1] = -Im r[n] / M ----
+  const float inv_m = 1.0f / (float)M;
+  float* y = a.y + (int64_t)c * a.Tp + g.toff;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int b = tid + j * T;
+    if (Q != 1 && (16 % Q) != 0 && b >= N2) continue;
+    const float2* const col = s + pad16(b);
+    v2f tk[Q];
+    tk[0] = V(col[0]);
+#pragma unroll
+    for (int k1 = 1; k1 < Q; ++k1) {
+      const int e = (j * k1) & 15;
+      const float2 wf = e == 0 ? wb[k1] : cmul(wb[k1], unit_root(e, 16));
+      tk[k1] = vcmul(V(col[k1 * ROW]), V(wf));
+    }
+#pragma unroll
+    for (int aa = 0; aa < NZ; ++aa) {
+      const int t = 2 * (b + N2 * aa);
+      v2f rr = tk[0];
+#pragma unroll
+      for (int k1 = 1; k1 < Q; ++k1) rr += mul_wq<Q>(tk[k1], k1 * aa);
+      v2f cv = rr * v2f{inv_m, -inv_m};
+      if (DL) cv += V(fadd[j][aa]);  // + the shared row's own convolution (the read's z was taken relative to it)
+      const v2f o = cv * g.sc_eval(0, r0[j][aa]);
+      if (t < L && t >= g.pv) {  // (SP: own positions only)
+        if (t + 1 < L) *reinterpret_cast<float2*>(y + t) = F(o);
+        else y[t] = o.x;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // rows of workgroup p (0..7): (0, 8) for p = 0, (p, 16 - p) otherwise
 __device__ __forceinline__ void f15_rows(int p, int& ka, int& kb) {
   ka = p;
@@ -784,31 +1152,78 @@ int launch_fft_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n
   return a.pv ? launch_fft_t2<LOGM, TAB, 1>(st, a, reads, n_reads, tw, spec) : launch_fft_t2<LOGM, TAB, 0>(st, a, reads, n_reads, tw, spec);
 }
 
-}  // namespace
 
-int launch_fft_twiddles(hipStream_t st, float* tw) {
-  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_N / 256), dim3(256), 0, st, reinterpret_cast<float2*>(tw));
+template <int Q>
+constexpr int split_tw_off() { return Q == 3 ? FFT_TW3_OFF : 0; }
+template <int LOGN, int Q>
+constexpr int split_tw_step() { return (Q == 3 ? FFT_TW3_N : FFT_TW_N) / (2 * SplitGeo<LOGN, Q>::M); }
+
+template <int LOGN, int Q>
+int launch_filter_q(hipStream_t st, const float* kf, int64_t kf_stride, int kf_taps, int D, const float2* tw, float2* spec) {
+  using G = SplitGeo<LOGN, Q>;
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fftq_filter_kernel<LOGN, Q>), G::smem);
+  hipLaunchKernelGGL((hyena_fftq_filter_kernel<LOGN, Q>), dim3(D), dim3(G::T), G::smem, st, kf, kf_stride, kf_taps, tw,
+                     tw + split_tw_off<Q>(), split_tw_step<LOGN, Q>(), spec);
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
-int fft_twiddle_count() { return FFT_TW_N; }
 
-int launch_hyena_fft_filter(hipStream_t st, int logm, const float* kf, int64_t kf_stride, int kf_taps, int D,
+template <int LOGN, int Q, bool TAB, int SP>
+int launch_fftq_t2(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  using G = SplitGeo<LOGN, Q>;
+  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fftq_kernel<LOGN, Q, TAB, SP>), G::smem);
+  hipLaunchKernelGGL((hyena_fftq_kernel<LOGN, Q, TAB, SP>), dim3(n_reads, a.D), dim3(G::T), G::smem, st, a, reads, tw,
+                     tw + split_tw_off<Q>(), split_tw_step<LOGN, Q>(), spec);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+template <int LOGN, int Q, bool TAB>
+int launch_fftq_t(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  if (a.pv && a.dbase) return launch_fftq_t2<LOGN, Q, TAB, 2>(st, a, reads, n_reads, tw, spec);
+  return a.pv ? launch_fftq_t2<LOGN, Q, TAB, 1>(st, a, reads, n_reads, tw, spec)
+              : launch_fftq_t2<LOGN, Q, TAB, 0>(st, a, reads, n_reads, tw, spec);
+}
+template <int LOGN, int Q>
+int launch_fftq(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  return a.tok ? launch_fftq_t<LOGN, Q, true>(st, a, reads, n_reads, tw, spec) : launch_fftq_t<LOGN, Q, false>(st, a, reads, n_reads, tw, spec);
+}
+template <int LOGM>
+int launch_fft_direct(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
+  return a.tok ? launch_fft_t<LOGM, true>(st, a, reads, n_reads, tw, spec) : launch_fft_t<LOGM, false>(st, a, reads, n_reads, tw, spec);
+}
+
+}  // namespace
+
+int launch_fft_twiddles(hipStream_t st, float* tw) {
+  float2* t2 = reinterpret_cast<float2*>(tw);
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW_N / 256), dim3(256), 0, st, t2, FFT_TW_N);
+  hipLaunchKernelGGL(fft_twiddle_kernel, dim3(FFT_TW3_N / 256), dim3(256), 0, st, t2 + FFT_TW3_OFF, FFT_TW3_N);
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+int fft_twiddle_count() { return FFT_TW_TOTAL; }
+
+int launch_hyena_fft_filter(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
                             const float* tw, float* spec) {
+  DC_REQUIRE(cls >= 0 && cls < kFftClasses, "FFT long convolution: no such size class");
+  const FftClassInfo& ci = kFftClass[cls];
   const float2* t2 = reinterpret_cast<const float2*>(tw);
   float2* s2 = reinterpret_cast<float2*>(spec);
-  switch (logm) {
-    case 10: return launch_filter_t<10>(st, kf, kf_stride, kf_taps, D, t2, s2);
-    case 11: return launch_filter_t<11>(st, kf, kf_stride, kf_taps, D, t2, s2);
-    case 12: return launch_filter_t<12>(st, kf, kf_stride, kf_taps, D, t2, s2);
-    case 13: return launch_filter_t<13>(st, kf, kf_stride, kf_taps, D, t2, s2);
-    case 14: return launch_filter_t<14>(st, kf, kf_stride, kf_taps, D, t2, s2);
-    case 15:
+  switch (ci.q * 100000 + ci.points) {
+    case 100000 + 1024: return launch_filter_t<10>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 100000 + 2048: return launch_filter_t<11>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 100000 + 4096: return launch_filter_t<12>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 100000 + 8192: return launch_filter_t<13>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 100000 + 16384: return launch_filter_t<14>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 200000 + 8192: return launch_filter_q<12, 2>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 300000 + 12288: return launch_filter_q<12, 3>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 400000 + 16384: return launch_filter_q<12, 4>(st, kf, kf_stride, kf_taps, D, t2, s2);
+    case 32768:
       hipLaunchKernelGGL(hyena_fft15_filter_kernel, dim3(8, D), dim3(256), f15_smem(), st, kf, kf_stride, kf_taps, t2, s2);
       DC_LAUNCH_CHECK();
       return DC_OK;
   }
-  set_error("FFT long convolution: unsupported size 2^%d", logm);
+  set_error("FFT long convolution: unsupported size class %d", cls);
   return DC_ERR_UNSUPPORTED;
 }
 
@@ -845,21 +1260,29 @@ int launch_hyena_fft15(hipStream_t st, const HyenaArgs& a, const int32_t* reads,
   return DC_OK;
 }
 
-int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int logm, const int32_t* reads, int n_reads, const float* tw,
+int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int cls, const int32_t* reads, int n_reads, const float* tw,
                      const float* spec) {
   if (n_reads <= 0) return DC_OK;
   DC_REQUIRE(a.ntok && a.toff && a.u && a.y && a.sw && a.sb && reads && tw && spec, "FFT long convolution: null argument");
+  DC_REQUIRE(cls >= 0 && cls < kFftClasses, "FFT long convolution: no such size class");
+  const FftClassInfo& ci = kFftClass[cls];
   const float2* t2 = reinterpret_cast<const float2*>(tw);
   const float2* s2 = reinterpret_cast<const float2*>(spec);
-  const bool tab = a.tok != nullptr;
-  switch (logm) {
-    case 10: return tab ? launch_fft_t<10, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<10, false>(st, a, reads, n_reads, t2, s2);
-    case 11: return tab ? launch_fft_t<11, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<11, false>(st, a, reads, n_reads, t2, s2);
-    case 12: return tab ? launch_fft_t<12, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<12, false>(st, a, reads, n_reads, t2, s2);
-    case 13: return tab ? launch_fft_t<13, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<13, false>(st, a, reads, n_reads, t2, s2);
-    case 14: return tab ? launch_fft_t<14, true>(st, a, reads, n_reads, t2, s2) : launch_fft_t<14, false>(st, a, reads, n_reads, t2, s2);
+  // 4 096 points: the staged kernel's one-row form (Q = 1) measured 10 % faster than the round-2 kernel on this class
+  // (profiles/r05b_fft_class_sweep.jsonl); DC_FFT_STAGED1=0 keeps the latter (A/B)
+  static const bool staged1 = !(getenv("DC_FFT_STAGED1") && atoi(getenv("DC_FFT_STAGED1")) == 0);
+  if (staged1 && ci.q == 1 && ci.points == 4096) return launch_fftq<12, 1>(st, a, reads, n_reads, t2, s2);
+  switch (ci.q * 100000 + ci.points) {
+    case 100000 + 1024: return launch_fft_direct<10>(st, a, reads, n_reads, t2, s2);
+    case 100000 + 2048: return launch_fft_direct<11>(st, a, reads, n_reads, t2, s2);
+    case 100000 + 4096: return launch_fft_direct<12>(st, a, reads, n_reads, t2, s2);
+    case 100000 + 8192: return launch_fft_direct<13>(st, a, reads, n_reads, t2, s2);
+    case 100000 + 16384: return launch_fft_direct<14>(st, a, reads, n_reads, t2, s2);
+    case 200000 + 8192: return launch_fftq<12, 2>(st, a, reads, n_reads, t2, s2);
+    case 300000 + 12288: return launch_fftq<12, 3>(st, a, reads, n_reads, t2, s2);
+    case 400000 + 16384: return launch_fftq<12, 4>(st, a, reads, n_reads, t2, s2);
   }
-  set_error("FFT long convolution: unsupported size 2^%d", logm);
+  set_error("FFT long convolution: size class %d has no in-LDS kernel", cls);
   return DC_ERR_UNSUPPORTED;
 }
 

@@ -368,6 +368,11 @@ class HipModel:
         """Reads with more than `min_tokens` tokens take the O(L log L) FFT long convolution (default 2560)."""
         _lib.check(_lib.lib().dc_model_set_fft_threshold(self._h, int(min_tokens)))
 
+    def set_fft_split(self, on: bool):
+        """True (default): split / mixed-radix FFT size classes (3 passes, 3 x and 5 x 2^k points); False: the power-of-two
+        transforms of rounds 2-4 (the A/B reference)."""
+        _lib.check(_lib.lib().dc_model_set_fft_split(self._h, 1 if on else 0))
+
     def set_mlp_fusion(self, level):
         """fp16x3.  0 / False: fc1 and fc2 as two GEMM launches; 1: fc1 -> GELU -> fc2 as one kernel;
         2 / True (default): that kernel also runs the GEMM that consumes LayerNorm(its output) -- the next

@@ -320,12 +320,20 @@ int dc_model_set_mlp_fusion(dc_model* m, int32_t level);
 /* Long convolution of the Hyena operator (the reference's `fftconv`, HF-Hub code called at
  * deepchopper/models/llm/hyena.py:34-41).  Reads of up to `min_tokens` tokens run the block-Toeplitz MFMA kernel
  * (O(L^2), measured faster below ~2.5k tokens); longer reads (up to 16 384 tokens) run an in-LDS radix-16 FFT
- * convolution (O(L log L), fp32 like the reference; five padded sizes 2^10 .. 2^14 complex points).  Default 2560
+ * convolution (O(L log L), fp32 like the reference; padded sizes 1 024 .. 16 384 complex points, see
+ * dc_model_set_fft_split).  Default 2560
  * ($DC_FFT_MIN): inside the 2^12 bucket the FFT costs the same for every read while the Toeplitz cost grows with
  * L^2, they cross near 2 550 tokens; min_tokens >= 256 (DC_ERR_ARG below); a value above the model's context length
  * disables the FFT path.  Same results within the forward's tolerance either way
  * (tests/test_gpu_forward.py::test_fft_long_convolution_matches_toeplitz_and_oracle). */
 int dc_model_set_fft_threshold(dc_model* m, int32_t min_tokens);
+
+/* Size classes of that FFT convolution.  on != 0 (default; $DC_FFT_SPLIT=0 for the other): transforms above 4 096 points are
+ * split once, M = Q x 4096 (Q = 2, 3, 4 rows in LDS, three radix-16 passes each instead of four; the zero half of the packed
+ * input and the unused half of the output are never computed): classes of 1 024, 2 048, 4 096, 8 192, 12 288, 16 384 points.
+ * on == 0: the power-of-two transforms of rounds 2-4 (1 024 .. 16 384 points, four passes for 2^13 / 2^14).  Same results to
+ * fp32 rounding (tests/test_gpu_forward.py::test_split_fft_classes_match_the_power_of_two_transforms). */
+int dc_model_set_fft_split(dc_model* m, int32_t on);
 
 /* fp16x3 range guard.  Mode 2 of dc_model_set_gemm_mode ("fp16x3") splits operands into two fp16 terms
  * (22 significant bits, three MFMAs); an activation whose magnitude exceeds 65504 cannot be represented

@@ -27,6 +27,14 @@ def env(hip_lib, request):
     return torch, ops, sd, model
 
 
+def _fft_points(n_tokens: int) -> int:
+    """Transform size (complex points) of the FFT size class a sequence of n_tokens takes (csrc/forward.h: kFftClass)."""
+    for m in (1024, 2048, 4096, 8192, 12288, 16384):
+        if n_tokens <= m:
+            return m
+    return 32768
+
+
 def _inputs(rng, B, L, pad_max=0):
     ids = rng.integers(7, 12, (B, L)).astype(np.int64)
     q = rng.integers(1, 41, (B, L)).astype(np.float32)
@@ -662,12 +670,13 @@ def test_precision_robustness_vs_float64(hip_lib, case):
     model.close()
 
 
-@pytest.mark.parametrize("L", [1500, 2048, 2049, 3000, 4097, 8192, 10001, 16384])
+@pytest.mark.parametrize("L", [1500, 2048, 2049, 3000, 4096, 4097, 8192, 8193, 10001, 12288, 12289, 16384])
 def test_fft_long_convolution_matches_toeplitz_and_oracle(env, L):
     """The O(L log L) FFT long convolution (reads above the length threshold, csrc/hyena_fft.hip) against the
-    block-Toeplitz MFMA kernel of the same build and against the oracle's `fftconv`: every transform size
-    (2^11 .. 2^14 complex points), lengths at and next to the size boundaries, and a ragged batch in which short
-    reads keep the MFMA kernel while long ones take the FFT."""
+    block-Toeplitz MFMA kernel of the same build and against the oracle's `fftconv`: every size class (1 024 .. 16 384
+    complex points: one radix-16 transform up to 4 096, the split forms 2 x 4096, 3 x 4096, 4 x 4096 above), lengths at and
+    next to the class boundaries, and a ragged batch in which short reads keep the MFMA kernel while long ones take the
+    FFT."""
     torch, ops, sd, model = env
     from oracle import forward_ref as fr
 
@@ -701,6 +710,46 @@ def test_fft_long_convolution_matches_toeplitz_and_oracle(env, L):
         _check(out[0, L - Ls:], fr.forward(sd, i_s, q_s).numpy()[0])
     finally:
         model.set_fft_threshold(2560)  # the shipped default (forward_api.hip: fft_min_tokens)
+        model.set_profiling(False)
+
+
+def test_split_fft_classes_match_the_power_of_two_transforms(env):
+    """dc_model_set_fft_split: the split / mixed-radix size classes (default) against the power-of-two transforms of rounds
+    2-4 on one ragged launch that holds a read of every class (and one on the MFMA path): same logits to fp32 rounding, the
+    launch counts show which classes ran, and both are within the parity tolerance of the oracle."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(77)
+    lens = [900, 2600, 4096, 5000, 8192, 9000, 12288, 14000, 16384]
+    stride = max(lens)
+    ids = np.full((len(lens), stride), 4, np.uint8)
+    q = np.zeros((len(lens), stride), np.float32)
+    for r, n in enumerate(lens):
+        i_r, q_r = _inputs(rng, 1, n)
+        ids[r, :n], q[r, :n] = i_r[0], q_r[0]
+    first, ntok = np.zeros(len(lens), np.int32), np.array(lens, np.int32)
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    try:
+        outs, launches = {}, {}
+        for split in (False, True):
+            model.set_fft_split(split)
+            model.set_profiling(True)
+            model.profile_reset()
+            outs[split] = model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()
+            launches[split] = model.profile().get("hyena_fft", (0, 0))[1]
+            model.set_profiling(False)
+        # classes present: power of two 2^12, 2^13, 2^14 (3 per layer); split 4096, 8192, 12288, 16384 (4)
+        assert launches[False] == 4 * 3 and launches[True] == 4 * 4, launches
+        worst = 0.0
+        for r, n in enumerate(lens):
+            worst = max(worst, float(np.abs(outs[True][r, :n] - outs[False][r, :n]).max()))
+        assert worst < 1e-4, worst
+        for r in (3, 5, 7):  # one read per split form against the oracle
+            n = lens[r]
+            _check(outs[True][r, :n], fr.forward(sd, ids[r: r + 1, :n].astype(np.int64), q[r: r + 1, :n]).numpy()[0])
+    finally:
+        model.set_fft_split(True)
         model.set_profiling(False)
 
 
@@ -864,9 +913,8 @@ def test_shared_prefix_linear_form_equals_the_padded_launch(env, case):
         assert stages.get("hyena_pad_row", (0, 0))[1] == 4, stages  # one shared row, once per layer
         # FFT launches: one per layer and transform size among the reads THEMSELVES
         own = np.array([x for b in batches for x in b]) + 4
-        sizes = {int(np.ceil(np.log2(max(n, 1024)))) for n in own[(npad >= 4) & (own > 2560)]} | {
-            int(np.ceil(np.log2(max(n, 1024)))) for n in ntok[(npad < 4) & (ntok > 2560)]}
-        small = len({z for z in sizes if z <= 14})
+        sizes = {_fft_points(n) for n in own[(npad >= 4) & (own > 2560)]} | {_fft_points(n) for n in ntok[(npad < 4) & (ntok > 2560)]}
+        small = len({z for z in sizes if z <= 16384})
         assert stages.get("hyena_fft", (0, 0))[1] == 4 * small, (stages, sizes)  # (the shared row's own launch is inside "hyena_pad_row")
 
 
