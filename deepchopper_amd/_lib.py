@@ -95,6 +95,7 @@ _SIGNATURES = {
     "dc_model_set_mlp_fusion": (C.c_int, [vp, i32]),
     "dc_model_set_fft_threshold": (C.c_int, [vp, i32]),
     "dc_model_set_fft_split": (C.c_int, [vp, i32]),
+    "dc_pt_pack": (C.c_int, [vp, vp, vp, vp, i32, vp, i64, i64, i32, vp, vp, vp, i64]),
     "dc_model_overflow": (C.c_int, [vp, vp, C.POINTER(i32)]),
     "dc_model_set_overflow_target": (C.c_int, [vp, vp]),
     "dc_model_get_gemm_mode": (C.c_int, [vp, C.POINTER(i32)]),

@@ -252,6 +252,7 @@ def _predict(args, argv: list[str]) -> int:
     model_name = HUB_NAMES.get(args.model.lower(), args.model)
     model = DeepChopper.from_pretrained(model_name)
     pipe = PredictPipeline(model, smooth=_smooth_params(args))
+    t_ready = time.time()  # interpreter, torch, the libraries, weights on the GPU: everything before the first read
     out_dir = Path(args.output or "predictions")
     max_reads, max_bases = _chunk_limits(args, world)
     pipe_src = None
@@ -264,6 +265,7 @@ def _predict(args, argv: list[str]) -> int:
         chunks = rank_chunks(str(data_path), rank, world, max_reads, max_bases, args.max_sample, full_header=bool(args.chop))
     chunks = limit_batches(chunks, args.limit_batches)
     n_batches = n_reads = n_records = 0
+    t_streamed = pt_timers = None
     if args.chop:
         from .chop import predict_chop
 
@@ -299,12 +301,17 @@ def _predict(args, argv: list[str]) -> int:
     else:
         os.makedirs(out_dir / "0", exist_ok=True)
         tsv = open(out_dir / "0" / f"{rank}.intervals.tsv", "w") if args.native else None
-        # the 28 B/token wire format is pickled and written on worker threads (--threads; the reference writes from its one
-        # predict loop, callbacks.py:12-25): a fused launch is ~30 MB in ~85 files, and one thread's torch.save tops out near
-        # 400 MB/s -- 12 k reads/s -- next to a GPU path of 32 k
+        # the 28 B/token wire format is written on worker threads (--threads; the reference writes from its one predict loop,
+        # callbacks.py:12-25) by the native writer (include/deepchopper_io.h: dc_pt_*): a fused launch is ~85 files of ~1 MB,
+        # and torch.save -- byte-wise CRC-32, Python per file -- topped out near 750 MB/s over all threads next to a GPU path
+        # that produces 2.2 GB/s of `.pt` on a nanopore-like length mix.  DC_PT_WRITER=torch keeps torch.save (A/B)
         from concurrent.futures import ThreadPoolExecutor
 
-        pool = ThreadPoolExecutor(max(1, args.threads)) if not args.no_pt else None
+        from .predict import PtWriter
+
+        native_pt = os.environ.get("DC_PT_WRITER", "native") != "torch" and not args.no_pt
+        pool = ThreadPoolExecutor(max(1, args.threads)) if not args.no_pt and not native_pt else None
+        writer = PtWriter(threads=max(1, args.threads)) if native_pt else None
         pending: list = []
         try:
             # reference mode (-b): left-padded batches whose pad tokens run through the model, int64
@@ -317,23 +324,36 @@ def _predict(args, argv: list[str]) -> int:
                 # (--max-tokens budgets what a launch runs through the GEMMs: the reads' own tokens when the [PAD] runs are
                 #  shared, the padded rows otherwise)
                 chunks = fuse_chunks(chunks, max_reads=args.max_reads, max_tokens=args.max_tokens, padded=not pipe.shared_prefix)
-            for res in pipe.predict_stream(chunks, reference_padding=not args.native, ids_i64=not args.no_pt,
+            for res in pipe.predict_stream(chunks, reference_padding=not args.native, ids_i64=pool is not None,
                                            want_labels=not args.no_pt):
                 if tsv is not None:
                     iv, niv, lens = res["intervals"], res["n_intervals"], res["lengths"]
                     tsv.write("".join(
                         f"{name}\t{int(lens[r])}\t" + ",".join(f"{s}:{e}" for s, e in iv[r, : int(niv[r])].tolist()) + "\n"
                         for r, name in enumerate(res["names"])))
-                if not args.no_pt:  # one reference batch = one file, as CustomWriter writes them
+                if writer is not None:  # one reference batch = one file, as CustomWriter writes them
+                    n_batches += writer.submit(str(out_dir / "0"), rank, n_batches, res["device"], res["names"],
+                                               ready_event=res.get("ready_event"), truncated=res["truncated"])
+                elif not args.no_pt:
                     n_batches += write_pt_batches(str(out_dir / "0"), rank, n_batches, res["device"], res["names"], pool, pending)
                     while len(pending) > 4 * max(1, args.threads):  # bound the host copies waiting to be written
                         pending.pop(0).result()
                 else:
                     n_batches += len(res.get("sub_sizes") or [0])
                 n_reads += len(res["names"])
+            t_streamed = time.time()
             for f in pending:
                 f.result()  # (a failed write raises here)
+            if writer is not None:
+                w, writer = writer, None
+                w.close()   # (... or here)
+                pt_timers = {k: round(v, 3) for k, v in w.timers.items()}
         finally:
+            if writer is not None:
+                try:
+                    writer.close()
+                except Exception:  # the error that brought us here is the one to report
+                    pass
             if pool is not None:
                 pool.shutdown(wait=True)
             if tsv is not None:
@@ -342,6 +362,13 @@ def _predict(args, argv: list[str]) -> int:
         raise ValueError(f"No valid records found in {data_path}")
     logging.info("rank %d of %d: %d reads in %d batches", rank, world, n_reads, n_batches)
     report = {"rank": rank, "reads": n_reads, "batches": n_batches, "records": n_records, **_process_accounting(t_start)}
+    # where the wall time went: start-up (imports, weights, handles) | the stream (parse -> GPU -> results handed to the writers)
+    # | what the writers still had to finish behind the last launch
+    t_end = time.time()
+    if pt_timers is not None:
+        report["pt_writer_main_thread_s"] = pt_timers  # where the predict loop itself waited on the `.pt` path
+    report["phases_s"] = {"startup": round(t_ready - t_start, 3), "stream": round((t_streamed or t_end) - t_ready, 3),
+                          "drain": round(t_end - (t_streamed or t_end), 3)}
     if placed is not None:
         report.update({"cpuset": placed["cpuset"], "numa_node": placed["numa_node"], "torch_threads": torch.get_num_threads(),
                        "cpu_budget": placed.get("cpu_budget"), "capped_to_budget": placed.get("capped_to_budget")})

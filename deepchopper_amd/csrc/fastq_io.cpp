@@ -47,6 +47,23 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+namespace dcio {
+// the same thread-local message for the library's other translation units (pt_writer.cpp)
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace dcio
+
+namespace {
+
 constexpr size_t kBlock = 4u << 20;  // decompressed / plain bytes handed from the source thread per block
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,675 @@
+// The predict -> chop wire format written natively (include/deepchopper_io.h: dc_pt_*).
+//
+// Reference behaviour restated here (never its code):
+//   CustomWriter.write_on_batch_end            deepchopper/models/callbacks.py:12-25   torch.save(prediction_dict, "{rank}_{batch}.pt")
+//   the dict a predict step returns            deepchopper/models/basic_module.py      {prediction f32[B,L,2], target i64[B,L], seq i64[B,L],
+//                                                                                       qual f32[B,L], id i64[B,256]}
+//   the id row [len, truncated, ord(c)...]      deepchopper/models/llm/tokenizer.py:170-175 (+ the collator's int8 cast, :91)
+//   the consumer                               src/smooth/predict.rs:264-317 (candle_core::pickle::read_all: zip entry "*/data.pkl"
+//                                              + "*/data/<key>" storages)
+// torch.save's container is a ZIP of STORED entries: `<stem>/data.pkl` (pickle protocol 2; tensors are persistent-id
+// references to storages by key), `<stem>/data/<key>` (raw little-endian storage bytes, 64-byte aligned in the file),
+// `byteorder`, `version` and a few markers.  torch.save spends its time in a byte-wise CRC-32 and in Python; a fused launch
+// is ~85 files of ~1 MB.  Here a pool of threads builds every file of a launch in memory -- rows cut out of the launch's dense
+// host arrays, token ids / labels widened to int64, zlib's CRC-32 -- and writes it with one write().
+#include "../../include/deepchopper_io.h"
+
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+#include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include <algorithm>
+#include <cerrno>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace dcio {
+int fail(int code, const char* fmt, ...);  // fastq_io.cpp: sets the thread-local message of dc_io_last_error()
+}
+
+namespace {
+
+struct Bytes {
+  std::vector<uint8_t> v;
+  void u8(unsigned x) { v.push_back((uint8_t)x); }
+  void u16(unsigned x) {
+    u8(x & 255);
+    u8((x >> 8) & 255);
+  }
+  void u32(uint64_t x) {
+    u16((unsigned)(x & 0xffff));
+    u16((unsigned)((x >> 16) & 0xffff));
+  }
+  void raw(const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    v.insert(v.end(), b, b + n);
+  }
+  void str(const std::string& s) { raw(s.data(), s.size()); }
+};
+
+// ---- pickle protocol 2, exactly the opcode stream torch.save emits for this dict ----------------------------------
+struct Pickler {
+  Bytes b;
+  int memo = 0;
+  void put() {  // BINPUT / LONG_BINPUT
+    if (memo < 256) {
+      b.u8('q');
+      b.u8(memo);
+    } else {
+      b.u8('r');
+      b.u32(memo);
+    }
+    ++memo;
+  }
+  void get(int i) {  // BINGET (every memo index referenced here is < 256)
+    b.u8('h');
+    b.u8(i);
+  }
+  void unicode(const char* s) {
+    b.u8('X');
+    b.u32(strlen(s));
+    b.raw(s, strlen(s));
+    put();
+  }
+  void global(const char* module, const char* name) {
+    b.u8('c');
+    b.raw(module, strlen(module));
+    b.u8('\n');
+    b.raw(name, strlen(name));
+    b.u8('\n');
+    put();
+  }
+  void integer(int64_t x) {  // pickle.save_long, protocol 2
+    if (x >= 0 && x <= 0xff) {
+      b.u8('K');
+      b.u8((unsigned)x);
+    } else if (x >= 0 && x <= 0xffff) {
+      b.u8('M');
+      b.u16((unsigned)x);
+    } else if (x >= -0x80000000ll && x <= 0x7fffffffll) {
+      b.u8('J');
+      b.u32((uint32_t)(int32_t)x);
+    } else {  // LONG1: little-endian two's complement, minimal length
+      uint8_t le[9];
+      int n = 0;
+      int64_t y = x;
+      for (;;) {
+        le[n++] = (uint8_t)(y & 255);
+        const bool sign = (le[n - 1] & 0x80) != 0;
+        y >>= 8;
+        if ((y == 0 && !sign) || (y == -1 && sign)) break;
+      }
+      b.u8(0x8a);
+      b.u8(n);
+      b.raw(le, n);
+    }
+  }
+  void tuple_of(const int64_t* x, int n) {  // n = 2 or 3
+    for (int i = 0; i < n; ++i) integer(x[i]);
+    b.u8(n == 2 ? 0x86 : 0x87);
+    put();
+  }
+};
+
+// storage class memo indices as torch's pickler assigns them in this dict: 4 = FloatStorage (first use: prediction),
+// 15 = LongStorage (first use: target)
+std::vector<uint8_t> make_pickle(int64_t B, int64_t L) {
+  Pickler p;
+  p.b.u8(0x80);
+  p.b.u8(2);
+  p.b.u8('}');
+  p.put();  // 0
+  p.b.u8('(');
+  struct T {
+    const char* key;
+    bool is_float;
+    int dims;
+    int64_t shape[3];
+  } ts[5] = {{"prediction", true, 3, {B, L, 2}}, {"target", false, 2, {B, L, 0}}, {"seq", false, 2, {B, L, 0}},
+             {"qual", true, 2, {B, L, 0}},       {"id", false, 2, {B, 256, 0}}};
+  int m_rebuild = -1, m_storage = -1, m_float = -1, m_long = -1, m_cpu = -1, m_odict = -1;
+  for (int i = 0; i < 5; ++i) {
+    const T& t = ts[i];
+    int64_t numel = 1, stride[3];
+    for (int d = t.dims - 1; d >= 0; --d) {
+      stride[d] = numel;
+      numel *= t.shape[d];
+    }
+    p.unicode(t.key);
+    if (m_rebuild < 0) {
+      m_rebuild = p.memo;
+      p.global("torch._utils", "_rebuild_tensor_v2");
+    } else {
+      p.get(m_rebuild);
+    }
+    p.b.u8('(');
+    p.b.u8('(');
+    if (m_storage < 0) {
+      m_storage = p.memo;
+      p.unicode("storage");
+    } else {
+      p.get(m_storage);
+    }
+    int& m_cls = t.is_float ? m_float : m_long;
+    if (m_cls < 0) {
+      m_cls = p.memo;
+      p.global("torch", t.is_float ? "FloatStorage" : "LongStorage");
+    } else {
+      p.get(m_cls);
+    }
+    const char key[2] = {(char)('0' + i), 0};
+    p.unicode(key);
+    if (m_cpu < 0) {
+      m_cpu = p.memo;
+      p.unicode("cpu");
+    } else {
+      p.get(m_cpu);
+    }
+    p.integer(numel);
+    p.b.u8('t');
+    p.put();
+    p.b.u8('Q');   // BINPERSID
+    p.integer(0);  // storage offset
+    p.tuple_of(t.shape, t.dims);
+    p.tuple_of(stride, t.dims);
+    p.b.u8(0x89);  // requires_grad = False
+    if (m_odict < 0) {
+      m_odict = p.memo;
+      p.global("collections", "OrderedDict");
+    } else {
+      p.get(m_odict);
+    }
+    p.b.u8(')');
+    p.b.u8('R');
+    p.put();
+    p.b.u8('t');
+    p.put();
+    p.b.u8('R');
+    p.put();
+  }
+  p.b.u8('u');
+  p.b.u8('.');
+  return std::move(p.b.v);
+}
+
+// ---- CRC-32 (the ZIP one: reflected 0x04C11DB7) by carry-less multiplication ---------------------------------------
+// Folding as in Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ" (Intel, 2009): four 128-bit
+// lanes are multiplied by x^(512 +- 32) mod P and xored into the next 64 bytes, then folded to one lane (x^(128 +- 32)),
+// to 64 bits and reduced (Barrett).  Constants for the reflected polynomial.  zlib 1.2.11's table CRC runs at ~1 GB/s and was
+// the largest share of a file's cost; this one at > 10 GB/s.  Checked against zlib's on first use (and on every file's
+// pickle stream); a CPU without PCLMULQDQ or a mismatch keeps zlib's.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc_fold(__m128i x, __m128i k, __m128i next) {
+  return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), next);
+}
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t crc0, const uint8_t* p, size_t n) {
+  // n >= 64 and a multiple of 16
+  const __m128i k512 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll);  // x^(512-32), x^(512+32) mod P
+  const __m128i k128 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);  // x^(128-32), x^(128+32)
+  const __m128i k64 = _mm_set_epi64x(0, 0x0163cd6124ll);                // x^64
+  const __m128i kbar = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);  // mu, P
+  const __m128i lo32 = _mm_setr_epi32(-1, 0, -1, 0);
+  __m128i a = _mm_xor_si128(_mm_loadu_si128((const __m128i*)p), _mm_cvtsi32_si128((int)~crc0));
+  __m128i b = _mm_loadu_si128((const __m128i*)(p + 16)), c = _mm_loadu_si128((const __m128i*)(p + 32)),
+          d = _mm_loadu_si128((const __m128i*)(p + 48));
+  p += 64;
+  n -= 64;
+  for (; n >= 64; p += 64, n -= 64) {
+    a = crc_fold(a, k512, _mm_loadu_si128((const __m128i*)p));
+    b = crc_fold(b, k512, _mm_loadu_si128((const __m128i*)(p + 16)));
+    c = crc_fold(c, k512, _mm_loadu_si128((const __m128i*)(p + 32)));
+    d = crc_fold(d, k512, _mm_loadu_si128((const __m128i*)(p + 48)));
+  }
+  a = crc_fold(a, k128, b);
+  a = crc_fold(a, k128, c);
+  a = crc_fold(a, k128, d);
+  for (; n >= 16; p += 16, n -= 16) a = crc_fold(a, k128, _mm_loadu_si128((const __m128i*)p));
+  // 128 -> 64 bits
+  __m128i t = _mm_clmulepi64_si128(a, k128, 0x10);
+  a = _mm_xor_si128(_mm_srli_si128(a, 8), t);
+  t = _mm_srli_si128(a, 4);
+  a = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(a, lo32), k64, 0x00), t);
+  // Barrett reduction
+  t = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(a, lo32), kbar, 0x10), lo32);
+  a = _mm_xor_si128(a, _mm_clmulepi64_si128(t, kbar, 0x00));
+  return ~(uint32_t)_mm_extract_epi32(a, 1);
+}
+#endif
+
+uint32_t crc32_fast(const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+  static const bool ok = [] {
+    if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+    uint8_t t[4096 + 48];
+    uint32_t x = 12345;
+    for (auto& v : t) v = (uint8_t)((x = x * 1664525u + 1013904223u) >> 24);
+    for (size_t len : {(size_t)64, (size_t)80, (size_t)1024, (size_t)4096 + 48})
+      if (crc32_clmul(0, t, len) != (uint32_t)crc32_z(0L, t, len)) return false;
+    return true;
+  }();
+  if (ok && n >= 64) {
+    const size_t body = n & ~(size_t)15;
+    const uint32_t c = crc32_clmul(0, p, body);
+    return body == n ? c : (uint32_t)crc32_z(c, p + body, n - body);
+  }
+#endif
+  return (uint32_t)crc32_z(0L, p, n);
+}
+
+// ---- ZIP container (STORED entries, data 64-byte aligned as torch's writer pads it) -----------------------------------
+// A file is written with one writev(): the metadata stream (local headers, the small entries, the central directory) is
+// built in memory and cut where a storage goes; the storages themselves are the iovecs in between -- the pinned host copy
+// of what the GPU packed (dc_pt_submit_packed: nothing is copied or converted on the host, the CRC is the only pass over
+// the data), or a worker's conversion buffer (dc_pt_submit: dense host arrays).
+struct Entry {
+  std::string name;
+  uint32_t crc, size, offset;
+};
+
+// A worker's conversion buffer: 64-byte aligned, grown without zero-filling (every byte is written exactly once;
+// std::vector::resize would memset the megabyte the rows are copied into next)
+struct RawBuf {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  ~RawBuf() { free(p); }
+  bool reserve(size_t want) {
+    if (want <= cap) return true;
+    const size_t c = (want + (want >> 2) + 4095) & ~(size_t)4095;
+    uint8_t* q = (uint8_t*)aligned_alloc(64, c);
+    if (!q) return false;
+    free(p);
+    p = q;
+    cap = c;
+    return true;
+  }
+};
+
+struct Zip {
+  Bytes meta;                  // every byte of the file that is not a storage, in file order
+  std::vector<size_t> cuts;    // meta offsets at which storage k is spliced in
+  std::vector<Entry> entries;
+  size_t pos = 0;              // file offset reached so far
+  void header(const std::string& name, size_t size, uint32_t crc) {
+    size_t extra = 4;
+    extra += (64 - (pos + 30 + name.size() + extra) % 64) % 64;
+    entries.push_back({name, crc, (uint32_t)size, (uint32_t)pos});
+    meta.u32(0x04034b50u);
+    meta.u16(20);      // version needed
+    meta.u16(0x0800);  // UTF-8 names
+    meta.u16(0);       // stored
+    meta.u16(0);
+    meta.u16(0x21);    // 1980-01-01
+    meta.u32(crc);
+    meta.u32(size);
+    meta.u32(size);
+    meta.u16((unsigned)name.size());
+    meta.u16((unsigned)extra);
+    meta.str(name);
+    meta.u8('F');
+    meta.u8('B');
+    meta.u16((unsigned)(extra - 4));
+    for (size_t i = 4; i < extra; ++i) meta.u8(0);
+    pos += 30 + name.size() + extra;
+  }
+  void small(const std::string& name, const void* p, size_t n) {
+    header(name, n, crc32_fast((const uint8_t*)p, n));
+    meta.raw(p, n);
+    pos += n;
+  }
+  void storage(const std::string& name, size_t size, uint32_t crc) {  // its bytes follow here in the file
+    header(name, size, crc);
+    cuts.push_back(meta.v.size());
+    pos += size;
+  }
+  void finish() {
+    const size_t cd = pos;
+    const size_t m0 = meta.v.size();
+    for (const Entry& e : entries) {
+      meta.u32(0x02014b50u);
+      meta.u16(20);
+      meta.u16(20);
+      meta.u16(0x0800);
+      meta.u16(0);
+      meta.u16(0);
+      meta.u16(0x21);
+      meta.u32(e.crc);
+      meta.u32(e.size);
+      meta.u32(e.size);
+      meta.u16((unsigned)e.name.size());
+      meta.u16(0);
+      meta.u16(0);
+      meta.u16(0);
+      meta.u16(0);
+      meta.u32(0);
+      meta.u32(e.offset);
+      meta.str(e.name);
+    }
+    const size_t cd_size = meta.v.size() - m0;
+    meta.u32(0x06054b50u);
+    meta.u16(0);
+    meta.u16(0);
+    meta.u16((unsigned)entries.size());
+    meta.u16((unsigned)entries.size());
+    meta.u32(cd_size);
+    meta.u32(cd);
+    meta.u16(0);
+    pos += meta.v.size() - m0;
+  }
+};
+
+struct Group;
+
+struct FileJob {
+  Group* g;
+  int index;  // file of the group
+};
+
+struct Group {
+  int64_t ticket = 0;
+  std::string dir;
+  int rank = 0;
+  int64_t first_index = 0;
+  std::vector<int32_t> row0, n_rows, col0;  // packed: col0 holds the file's columns L
+  // dense host arrays of the launch (dc_pt_submit) ...
+  const float* logits = nullptr;
+  const int8_t* labels = nullptr;
+  const uint8_t* ids = nullptr;
+  const float* quals = nullptr;
+  int64_t stride = 0;
+  // ... or the payloads the GPU packed (dc_pt_submit_packed): file i's storages 0..3 back to back at packed + pay_off[i]
+  const uint8_t* packed = nullptr;
+  std::vector<int64_t> pay_off;
+  std::vector<int64_t> id_rows;  // [rows of the launch][256]
+  int remaining = 0;
+  int err = 0;
+  std::string err_msg;
+};
+
+int writev_all(int fd, std::vector<iovec>& iov) {
+  size_t k = 0;
+  while (k < iov.size()) {
+    const int cnt = (int)std::min<size_t>(iov.size() - k, 64);
+    ssize_t w = ::writev(fd, iov.data() + k, cnt);
+    if (w < 0) {
+      if (errno == EINTR) continue;
+      return -1;
+    }
+    while (w > 0 && k < iov.size()) {
+      if ((size_t)w >= iov[k].iov_len) {
+        w -= (ssize_t)iov[k].iov_len;
+        ++k;
+      } else {
+        iov[k].iov_base = (uint8_t*)iov[k].iov_base + w;
+        iov[k].iov_len -= (size_t)w;
+        w = 0;
+      }
+    }
+    while (k < iov.size() && iov[k].iov_len == 0) ++k;
+  }
+  return 0;
+}
+
+// One `{rank}_{index}.pt`.  Returns 0 or fills `msg`.
+int write_one(const Group& g, int i, RawBuf& buf, std::string& msg) {
+  const int64_t B = g.n_rows[i], r0 = g.row0[i];
+  const int64_t L = g.packed ? g.col0[i] : g.stride - g.col0[i];
+  const std::string stem = std::to_string(g.rank) + "_" + std::to_string(g.first_index + i);
+  const std::string path = g.dir + "/" + stem + ".pt";
+  const size_t len[5] = {(size_t)(B * L * 8), (size_t)(B * L * 8), (size_t)(B * L * 8), (size_t)(B * L * 4), (size_t)(B * 2048)};
+  if ((uint64_t)B * L * 28 + (uint64_t)B * 2048 + 65536 >= 0xffff0000ull) {
+    msg = path + ": a .pt file of 4 GiB or more needs ZIP64, which this writer does not emit";
+    return 1;
+  }
+  const uint8_t* sec[5];
+  if (g.packed) {
+    const uint8_t* base = g.packed + g.pay_off[i];
+    sec[0] = base;
+    sec[1] = sec[0] + len[0];
+    sec[2] = sec[1] + len[1];
+    sec[3] = sec[2] + len[2];
+  } else {
+    const int64_t c0 = g.col0[i];
+    if (!buf.reserve(len[0] + len[1] + len[2] + len[3])) {
+      msg = path + ": out of memory";
+      return 1;
+    }
+    uint8_t* d0 = buf.p;
+    int64_t* d1 = reinterpret_cast<int64_t*>(d0 + len[0]);
+    int64_t* d2 = d1 + B * L;
+    uint8_t* d3 = reinterpret_cast<uint8_t*>(d2 + B * L);
+    for (int64_t r = 0; r < B; ++r) {
+      const int64_t src = (r0 + r) * g.stride + c0;
+      memcpy(d0 + (size_t)(r * L * 8), g.logits + src * 2, (size_t)(L * 8));  // prediction f32 [B, L, 2]
+      const int8_t* sl = g.labels + src;                                        // target i64 [B, L] (-100 = ignore)
+      const uint8_t* si = g.ids + src;                                          // seq i64 [B, L]
+      for (int64_t c = 0; c < L; ++c) d1[r * L + c] = sl[c];
+      for (int64_t c = 0; c < L; ++c) d2[r * L + c] = si[c];
+      memcpy(d3 + (size_t)(r * L * 4), g.quals + src, (size_t)(L * 4));       // qual f32 [B, L]
+    }
+    sec[0] = d0;
+    sec[1] = reinterpret_cast<const uint8_t*>(d1);
+    sec[2] = reinterpret_cast<const uint8_t*>(d2);
+    sec[3] = d3;
+  }
+  sec[4] = reinterpret_cast<const uint8_t*>(g.id_rows.data() + (size_t)r0 * 256);  // id i64 [B, 256]
+  uint32_t crc[5];
+  for (int k = 0; k < 5; ++k) crc[k] = crc32_fast(sec[k], len[k]);
+
+  Zip z;
+  z.meta.v.reserve(4096);
+  const std::vector<uint8_t> pk = make_pickle(B, L);
+  z.small(stem + "/data.pkl", pk.data(), pk.size());
+  z.small(stem + "/.format_version", "1", 1);
+  z.small(stem + "/.storage_alignment", "64", 2);
+  z.small(stem + "/byteorder", "little", 6);
+  for (int k = 0; k < 5; ++k) z.storage(stem + "/data/" + std::to_string(k), len[k], crc[k]);
+  z.small(stem + "/version", "3\n", 2);
+  {  // 40 decimal digits, as torch writes; its readers do not look at it
+    char sid[48];
+    uint64_t h = 1469598103934665603ull;
+    for (const Entry& e : z.entries) h = (h ^ e.crc) * 1099511628211ull;
+    snprintf(sid, sizeof sid, "%020llu%020llu", (unsigned long long)h, (unsigned long long)(h * 0x9E3779B97F4A7C15ull));
+    z.small(stem + "/.data/serialization_id", sid, 40);
+  }
+  z.finish();
+  std::vector<iovec> iov;
+  size_t m = 0;
+  for (int k = 0; k < 5; ++k) {
+    iov.push_back({z.meta.v.data() + m, z.cuts[k] - m});
+    iov.push_back({const_cast<uint8_t*>(sec[k]), len[k]});
+    m = z.cuts[k];
+  }
+  iov.push_back({z.meta.v.data() + m, z.meta.v.size() - m});
+  const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+  if (fd < 0) {
+    msg = path + ": " + strerror(errno);
+    return 1;
+  }
+  const int rc = writev_all(fd, iov);
+  const int e = errno;
+  if (::close(fd) != 0 && rc == 0) {
+    msg = path + ": " + strerror(errno);
+    return 1;
+  }
+  if (rc) {
+    msg = path + ": " + strerror(e);
+    return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+struct dc_pt_writer {
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::deque<FileJob> jobs;
+  std::deque<std::unique_ptr<Group>> groups;  // oldest first
+  std::vector<std::thread> threads;
+  int64_t next_ticket = 1;
+  bool stop = false;
+
+  void worker() {
+    RawBuf buf;
+    for (;;) {
+      FileJob j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return stop || !jobs.empty(); });
+        if (jobs.empty()) return;
+        j = jobs.front();
+        jobs.pop_front();
+      }
+      std::string msg;
+      const int rc = write_one(*j.g, j.index, buf, msg);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc && !j.g->err) {
+          j.g->err = rc;
+          j.g->err_msg = msg;
+        }
+        if (--j.g->remaining == 0) cv_done.notify_all();
+      }
+    }
+  }
+};
+
+extern "C" {
+
+int dc_pt_open(int threads, dc_pt_writer** out) {
+  if (!out) return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_open: null argument");
+  auto* w = new dc_pt_writer();
+  const int n = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+  for (int i = 0; i < n; ++i) w->threads.emplace_back([w] { w->worker(); });
+  *out = w;
+  return 0;
+}
+
+// id rows: [len(id), truncated, ord(c)...] clipped / zero padded to 256 (tokenizer.py:170-175); the reference's collator casts
+// them to int8 (tokenizer.py:91) and fails on anything above 127
+static int build_id_rows(Group& g, int64_t n_total_rows, const char* names, const int64_t* name_offsets, const uint8_t* truncated) {
+  g.id_rows.assign((size_t)n_total_rows * 256, 0);
+  for (int64_t r = 0; r < n_total_rows; ++r) {
+    const int64_t len = name_offsets[r + 1] - name_offsets[r];
+    const uint8_t* s = (const uint8_t*)names + name_offsets[r];
+    int64_t* row = g.id_rows.data() + (size_t)r * 256;
+    bool bad = len > 127;
+    row[0] = len;
+    row[1] = truncated[r] ? 1 : 0;
+    for (int64_t c = 0; c < len && c + 2 < 256; ++c) {
+      row[c + 2] = s[c];
+      bad |= s[c] > 127;
+    }
+    if (bad) return dcio::fail(DC_FQ_ERR_FORMAT, "value cannot be converted to type int8 without overflow");
+  }
+  return 0;
+}
+
+static int enqueue(dc_pt_writer* w, std::unique_ptr<Group> g, int n_files, int64_t* ticket_out) {
+  std::lock_guard<std::mutex> lk(w->mu);
+  g->ticket = w->next_ticket++;
+  g->remaining = n_files;
+  if (ticket_out) *ticket_out = g->ticket;
+  Group* gp = g.get();
+  w->groups.push_back(std::move(g));
+  for (int i = 0; i < n_files; ++i) w->jobs.push_back({gp, i});
+  w->cv_job.notify_all();
+  return 0;
+}
+
+int dc_pt_submit(dc_pt_writer* w, const char* dir, int32_t rank, int64_t first_index, int32_t n_files, const int32_t* row0,
+                 const int32_t* n_rows, const int32_t* col0, const float* logits, const int8_t* labels, const uint8_t* ids,
+                 const float* quals, int64_t n_total_rows, int64_t row_stride, const char* names, const int64_t* name_offsets,
+                 const uint8_t* truncated, int64_t* ticket_out) {
+  if (!w || !dir || n_files < 0 || (n_files && (!row0 || !n_rows || !col0 || !logits || !labels || !ids || !quals || !names ||
+                                                !name_offsets || !truncated)))
+    return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_submit: null argument");
+  auto g = std::make_unique<Group>();
+  g->dir = dir;
+  g->rank = rank;
+  g->first_index = first_index;
+  g->row0.assign(row0, row0 + n_files);
+  g->n_rows.assign(n_rows, n_rows + n_files);
+  g->col0.assign(col0, col0 + n_files);
+  for (int i = 0; i < n_files; ++i)
+    if (row0[i] < 0 || n_rows[i] < 1 || (int64_t)row0[i] + n_rows[i] > n_total_rows || col0[i] < 0 || col0[i] >= row_stride)
+      return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_submit: file %d cuts rows [%d, +%d) from column %d out of a [%lld, %lld] launch", i,
+                        row0[i], n_rows[i], col0[i], (long long)n_total_rows, (long long)row_stride);
+  g->logits = logits;
+  g->labels = labels;
+  g->ids = ids;
+  g->quals = quals;
+  g->stride = row_stride;
+  if (int rc = build_id_rows(*g, n_total_rows, names, name_offsets, truncated)) return rc;
+  return enqueue(w, std::move(g), n_files, ticket_out);
+}
+
+int dc_pt_submit_packed(dc_pt_writer* w, const char* dir, int32_t rank, int64_t first_index, int32_t n_files, const int32_t* row0,
+                        const int32_t* n_rows, const int32_t* n_cols, const int64_t* payload_offset, const void* payload,
+                        int64_t payload_bytes, int64_t n_total_rows, const char* names, const int64_t* name_offsets,
+                        const uint8_t* truncated, int64_t* ticket_out) {
+  if (!w || !dir || n_files < 0 || (n_files && (!row0 || !n_rows || !n_cols || !payload_offset || !payload || !names ||
+                                                !name_offsets || !truncated)))
+    return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_submit_packed: null argument");
+  auto g = std::make_unique<Group>();
+  g->dir = dir;
+  g->rank = rank;
+  g->first_index = first_index;
+  g->row0.assign(row0, row0 + n_files);
+  g->n_rows.assign(n_rows, n_rows + n_files);
+  g->col0.assign(n_cols, n_cols + n_files);
+  g->pay_off.assign(payload_offset, payload_offset + n_files);
+  for (int i = 0; i < n_files; ++i)
+    if (row0[i] < 0 || n_rows[i] < 1 || (int64_t)row0[i] + n_rows[i] > n_total_rows || n_cols[i] < 1 || payload_offset[i] < 0 ||
+        payload_offset[i] + (int64_t)n_rows[i] * n_cols[i] * 28 > payload_bytes)
+      return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_submit_packed: file %d ([%d, %d] at byte %lld) does not fit a payload of %lld bytes", i,
+                        n_rows[i], n_cols[i], (long long)payload_offset[i], (long long)payload_bytes);
+  g->packed = (const uint8_t*)payload;
+  if (int rc = build_id_rows(*g, n_total_rows, names, name_offsets, truncated)) return rc;
+  return enqueue(w, std::move(g), n_files, ticket_out);
+}
+
+int dc_pt_wait(dc_pt_writer* w, int64_t ticket) {
+  if (!w) return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_wait: null writer");
+  std::unique_lock<std::mutex> lk(w->mu);
+  int rc = 0;
+  std::string msg;
+  while (!w->groups.empty() && w->groups.front()->ticket <= ticket) {
+    Group* g = w->groups.front().get();
+    w->cv_done.wait(lk, [&] { return g->remaining == 0; });
+    if (g->err && !rc) {
+      rc = DC_FQ_ERR_IO;
+      msg = g->err_msg;
+    }
+    w->groups.pop_front();
+  }
+  lk.unlock();
+  return rc ? dcio::fail(rc, "%s", msg.c_str()) : 0;
+}
+
+int dc_pt_close(dc_pt_writer* w) {
+  if (!w) return 0;
+  const int rc = dc_pt_wait(w, INT64_MAX);
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->stop = true;
+  }
+  w->cv_job.notify_all();
+  for (auto& t : w->threads) t.join();
+  delete w;
+  return rc;
+}
+
+}  // extern "C"

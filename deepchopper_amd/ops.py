@@ -49,6 +49,20 @@ def to_device(a: np.ndarray) -> torch.Tensor:
     return t.to(_dev(), non_blocking=False)
 
 
+def pt_pack(logits, labels, input_ids, input_quals, table: np.ndarray, out: torch.Tensor) -> None:
+    """dc_pt_pack on the current stream: the storages data/0..3 of every `.pt` file of a fused launch, cut out of the launch's
+    dense device arrays and laid out as the files hold them, at the files' offsets of `out` (uint8, device).
+    `table`: int64 [n_files, 4] = row0, rows, first column, byte offset (multiple of 64) -- host array; uploaded here."""
+    table = np.ascontiguousarray(table, np.int64)
+    d_table = torch.from_numpy(table).pin_memory().to(logits.device, non_blocking=True)  # (no wait for the stream's earlier work)
+    n, stride = input_ids.shape
+    assert logits.is_contiguous() and labels.is_contiguous() and input_ids.is_contiguous() and input_quals.is_contiguous()
+    assert logits.shape == (n, stride, 2) and labels.dtype == torch.int8 and out.dtype == torch.uint8 and out.is_contiguous()
+    _lib.check(_lib.lib().dc_pt_pack(_stream(), _ptr(logits), _ptr(labels), _ptr(input_ids), int(input_ids.dtype == torch.int64),
+                                     _ptr(input_quals), n, stride, int(table.shape[0]), C.c_void_p(table.ctypes.data), _ptr(d_table),
+                                     _ptr(out), out.numel()))
+
+
 # ------------------------------------------------------------------------------------------
 # tokenise
 # ------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ from __future__ import annotations
 import os
 import queue
 import threading
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -361,6 +362,7 @@ class PredictPipeline:
                 "range_guard_rerun": bool(res.get("range_guard_rerun", False)),
                 "sub_sizes": res.get("sub_sizes"), "sub_cols": res.get("sub_cols"),
                 "device": res,  # device-resident tensors of the batch (logits, token matrices) for write_pt_batch
+                "ready_event": b["copied"],  # ... final behind this event (recorded on the copy stream after the batch's compute)
             }
             if want_labels:
                 out["pred"], out["smooth"] = own(host["pred"]), own(host["smooth"])
@@ -448,3 +450,196 @@ def write_pt_batches(dir_path: str, rank: int, first_index: int, res: dict, ids:
         for lo in range(0, len(subs), step):
             pending.append(pool.submit(save_range, lo, min(len(subs), lo + step), starts))
     return len(subs)
+
+
+class PtWriter:
+    """CustomWriter's `.pt` files (callbacks.py:12-25) written by libdeepchopper_io's thread pool (include/deepchopper_io.h:
+    dc_pt_*): the same container torch.save writes -- `torch.load` and the reference's `chop` read it -- without torch.save's
+    byte-wise CRC-32 and per-file Python.  `submit` hands over every reference batch of one (possibly fused) launch and
+    returns.
+    Device tensors (the pipeline's): the files' storages are cut out, converted and laid out ON THE GPU (dc_pt_pack), come to
+    pinned host memory in one asynchronous copy on the writer's own stream and go into the files without another pass; the
+    launch's device tensors and the pinned copy stay referenced here until the files are on disk (at most `max_inflight`
+    launches in flight).  Host tensors: the writer's threads cut the batches out of the dense arrays themselves."""
+
+    def __init__(self, threads: int = 4, max_inflight: int = 3):
+        import ctypes as C
+
+        from . import _iolib
+
+        self._io = _iolib
+        self._h = C.c_void_p()
+        _iolib.raise_for(_iolib.lib().dc_pt_open(int(max(1, threads)), C.byref(self._h)))
+        self._staged: list = []   # packed launches whose copy to the host is still running: (event, submit arguments, keep-alive)
+        self._pending: list = []  # (ticket, keep-alive, pinned buffer or None)
+        self._max = max(1, max_inflight)
+        self._stream = None       # pack + device -> host copies run beside the pipeline's compute stream
+        self._d_out = None        # device payload buffer (one: its producers and consumers are ordered on self._stream)
+        self._pinned_free: list = []
+        self.timers = {"pack_enqueue": 0.0, "pinned_alloc": 0.0, "wait_copy": 0.0, "wait_files": 0.0, "host_prep": 0.0}  # main-thread seconds
+
+    # ---- geometry shared by both forms ----
+    @staticmethod
+    def _files(res: dict, n: int):
+        subs = np.asarray(res.get("sub_sizes") or [n], np.int32)
+        cols = np.asarray(res.get("sub_cols") or [0] * len(subs), np.int32)
+        row0 = np.zeros(len(subs), np.int32)
+        np.cumsum(subs[:-1], out=row0[1:])
+        return row0, subs, cols
+
+    @staticmethod
+    def _names(ids: list[str]):
+        enc = [i.encode() for i in ids]
+        offs = np.zeros(len(ids) + 1, np.int64)
+        np.cumsum([len(e) for e in enc], out=offs[1:])
+        return b"".join(enc), offs
+
+    def submit(self, dir_path: str, rank: int, first_index: int, res: dict, ids: list[str], ready_event=None, truncated=None) -> int:
+        """`ready_event`: a CUDA event behind which the launch's device tensors are final (the pipeline's per-batch copy
+        event); without one the writer's stream waits for the current stream.  `truncated`: the reads' truncation flags on
+        the host (the pipeline's results carry them; read from the device here otherwise, which waits for the current stream)."""
+        os.makedirs(dir_path, exist_ok=True)
+        if truncated is None:
+            truncated = (res["tok"]["status"].cpu().numpy() & 1) != 0
+        truncated = np.ascontiguousarray(np.asarray(truncated).astype(np.uint8))
+        if res["logits"].is_cuda:
+            return self._submit_device(dir_path, rank, first_index, res, ids, ready_event, truncated)
+        return self._submit_host(dir_path, rank, first_index, res, ids, truncated)
+
+    def _submit_host(self, dir_path, rank, first_index, res, ids, truncated) -> int:
+        import ctypes as C
+
+        tok = res["tok"]
+        n = len(ids)
+        row0, subs, cols = self._files(res, n)
+        ids_t = tok["input_ids"]
+        if ids_t.dtype != torch.uint8:
+            ids_t = ids_t.to(torch.uint8)  # (token ids are < 16; the file's int64 is made by the writer)
+        host = (res["logits"].contiguous(), tok["labels"].contiguous(), ids_t.contiguous(), tok["input_quals"].contiguous())
+        assert host[0].dtype == torch.float32 and host[1].dtype == torch.int8 and host[3].dtype == torch.float32
+        stride = int(host[1].shape[1])
+        assert host[0].shape == (n, stride, 2) and host[2].shape == (n, stride) and host[3].shape == (n, stride)
+        names, offs = self._names(ids)
+        ticket = C.c_int64(0)
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        rc = self._io.lib().dc_pt_submit(self._h, os.fsencode(dir_path), int(rank), int(first_index), len(subs), ptr(row0), ptr(subs),
+                                         ptr(cols), C.c_void_p(host[0].data_ptr()), C.c_void_p(host[1].data_ptr()),
+                                         C.c_void_p(host[2].data_ptr()), C.c_void_p(host[3].data_ptr()), n, stride,
+                                         C.c_char_p(names), ptr(offs), ptr(truncated), C.byref(ticket))
+        self._io.raise_for(rc)
+        self._pending.append((ticket.value, host, None))
+        self._bound()
+        return len(subs)
+
+    def _submit_device(self, dir_path, rank, first_index, res, ids, ready_event, truncated) -> int:
+        from . import ops
+
+        tok = res["tok"]
+        n = len(ids)
+        row0, subs, cols = self._files(res, n)
+        logits, labels, ids_t, quals = res["logits"], tok["labels"], tok["input_ids"], tok["input_quals"]
+        stride = int(ids_t.shape[1])
+        n_cols = (stride - cols).astype(np.int32)
+        sizes = subs.astype(np.int64) * n_cols * 28
+        pay_off = np.zeros(len(subs), np.int64)
+        np.cumsum(((sizes + 63) // 64 * 64)[:-1], out=pay_off[1:])
+        total = int(pay_off[-1] + sizes[-1])
+        table = np.stack([row0.astype(np.int64), subs.astype(np.int64), cols.astype(np.int64), pay_off], axis=1)
+        dev = logits.device
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        t0 = time.perf_counter()
+        pinned = self._take_pinned(total)
+        t1 = time.perf_counter()
+        self.timers["pinned_alloc"] += t1 - t0
+        with torch.cuda.stream(self._stream):
+            if self._d_out is None or self._d_out.numel() < total:  # (allocated under the writer's stream: the caching allocator
+                self._d_out = None                                  #  hands a freed block back to that stream only)
+                self._d_out = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            if ready_event is not None:
+                self._stream.wait_event(ready_event)
+            else:
+                self._stream.wait_stream(torch.cuda.current_stream(dev))
+            ops.pt_pack(logits, labels, ids_t, quals, table, self._d_out)
+            pinned[:total].copy_(self._d_out[:total], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._stream)
+        t2 = time.perf_counter()
+        self.timers["pack_enqueue"] += t2 - t1
+        names, offs = self._names(ids)
+        self.timers["host_prep"] += time.perf_counter() - t2
+        args = (os.fsencode(dir_path), int(rank), int(first_index), row0, subs, n_cols, pay_off, total, n, names, offs, truncated)
+        self._staged.append((copied, args, (logits, labels, ids_t, quals), pinned))  # (the device tensors: until the copy is done)
+        self._flush(block=False)
+        self._bound()
+        return len(subs)
+
+    def _take_pinned(self, nbytes: int) -> torch.Tensor:
+        for i, t in enumerate(self._pinned_free):
+            if t.numel() >= nbytes:
+                return self._pinned_free.pop(i)
+        if len(self._pinned_free) >= 2:  # the ring has grown past what is in flight: let the smallest go
+            self._pinned_free.sort(key=lambda t: t.numel())
+            self._pinned_free.pop(0)
+        return torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+
+    def _flush(self, block: bool) -> None:
+        """Launches whose payload has arrived in host memory go to the writer threads (in order)."""
+        import ctypes as C
+
+        first = True
+        while self._staged and ((block and first) or self._staged[0][0].query()):
+            first = False
+            copied, args, _dev_keep, pinned = self._staged.pop(0)
+            t0 = time.perf_counter()
+            copied.synchronize()
+            self.timers["wait_copy"] += time.perf_counter() - t0
+            d, rank, first, row0, subs, n_cols, pay_off, total, n, names, offs, truncated = args
+            ticket = C.c_int64(0)
+            ptr = lambda a: C.c_void_p(a.ctypes.data)
+            rc = self._io.lib().dc_pt_submit_packed(self._h, d, rank, first, len(subs), ptr(row0), ptr(subs), ptr(n_cols), ptr(pay_off),
+                                                    C.c_void_p(pinned.data_ptr()), total, n, C.c_char_p(names), ptr(offs),
+                                                    ptr(truncated), C.byref(ticket))
+            if rc:
+                self._pinned_free.append(pinned)
+            self._io.raise_for(rc)
+            self._pending.append((ticket.value, None, pinned))
+
+    def _bound(self) -> None:
+        while len(self._staged) + len(self._pending) > self._max:
+            if self._pending:
+                self._wait_oldest()
+            else:
+                self._flush(block=True)
+
+    def _wait_oldest(self) -> None:
+        ticket, _keep, pinned = self._pending.pop(0)
+        t0 = time.perf_counter()
+        try:
+            self._io.raise_for(self._io.lib().dc_pt_wait(self._h, ticket))
+        finally:
+            self.timers["wait_files"] += time.perf_counter() - t0
+            if pinned is not None:
+                self._pinned_free.append(pinned)
+
+    def close(self) -> None:
+        """Waits for every file; a failed write raises here."""
+        if self._h:
+            try:
+                while self._staged:
+                    self._flush(block=True)
+            finally:
+                h, self._h = self._h, None
+                try:
+                    rc = self._io.lib().dc_pt_close(h)  # returns only when nothing reads the host copies any more
+                finally:
+                    self._pending.clear()
+                    self._staged.clear()
+                    self._pinned_free.clear()
+            self._io.raise_for(rc)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

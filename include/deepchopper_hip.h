@@ -335,6 +335,23 @@ int dc_model_set_fft_threshold(dc_model* m, int32_t min_tokens);
  * fp32 rounding (tests/test_gpu_forward.py::test_split_fft_classes_match_the_power_of_two_transforms). */
 int dc_model_set_fft_split(dc_model* m, int32_t on);
 
+/* The predict -> chop wire format, device half (the reference: CustomWriter.write_on_batch_end = torch.save of
+ * {prediction f32[B,L,2], target i64[B,L], seq i64[B,L], qual f32[B,L], id i64[B,256]} per batch,
+ * deepchopper/models/callbacks.py:12-25).  The reference batches of a fused launch lie in the launch's dense
+ * [n_rows][row_stride] arrays (logits f32 x 2, labels i8, token ids u8 or i64, qualities f32), batch i in rows
+ * [row0, row0 + B) from column c0 on (its own left padding starts there; L = row_stride - c0).  dc_pt_pack writes, for
+ * every file i, the storages `data/0..3` exactly as the `.pt` file holds them -- prediction f32[B][L][2] | target i64[B][L] |
+ * seq i64[B][L] | qual f32[B][L], 28 B per position, ids and labels widened here -- back to back at d_out + offset_i.
+ *   file table  int64[n_files][4] = {row0, B, c0, offset_i (bytes, a multiple of 64)}: the HOST copy is validated
+ *               (rows / columns inside the launch, payload inside out_bytes, < 2^31 positions per file), the DEVICE copy
+ *               is what the kernel reads.
+ * One launch on `stream`; d_out then goes to pinned host memory in one copy and into the files without another pass over
+ * it (include/deepchopper_io.h: dc_pt_submit_packed).  On a nanopore-like length mix the dense arrays are four times
+ * what the files hold; cutting the batches out on the host moved 12.6 GB over PCIe for 5.8 GB of files. */
+int dc_pt_pack(void* stream, const float* d_logits, const int8_t* d_labels, const void* d_ids, int32_t ids_i64,
+               const float* d_quals, int64_t n_rows, int64_t row_stride, int32_t n_files, const int64_t* h_file_table,
+               const int64_t* d_file_table, void* d_out, int64_t out_bytes);
+
 /* fp16x3 range guard.  Mode 2 of dc_model_set_gemm_mode ("fp16x3") splits operands into two fp16 terms
  * (22 significant bits, three MFMAs); an activation whose magnitude exceeds 65504 cannot be represented
  * and bumps a device counter.  Synchronises `stream`, returns the number of workgroups that saw such a

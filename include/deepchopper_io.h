@@ -15,6 +15,7 @@
  *                                 write_fq_parallel_for_noodle_record  src/output/writefq.rs:252-276
  *                                 and the chop driver                  src/bin/predict.rs:266-270
  *   dc_bgzf_write_fastq           fastq::io::Writer::write_record ("@name\nseq\n+\nqual\n") over it
+ *   dc_pt_open/submit/wait/close  CustomWriter.write_on_batch_end = torch.save   deepchopper/models/callbacks.py:12-25
  *
  * Conventions: every function returns 0 on success, non-zero on failure with a thread-local message in
  * dc_io_last_error().  Buffers are caller-owned; the only allocations the caller must release are the
@@ -157,6 +158,43 @@ int dc_chop_write_chunk(dc_bgzf_writer* w, const dc_chop_params* p, int64_t n, c
                         const int32_t* n_intervals, const int32_t* intervals, int32_t max_intervals,
                         const int32_t* n_keep, const int32_t* keep, int32_t max_keep,
                         int32_t* records_per_read, int64_t* n_records_out);
+
+/* ---- the predict -> chop wire format ---------------------------------------------------------------
+ * CustomWriter.write_on_batch_end (deepchopper/models/callbacks.py:12-25) = torch.save of the predict step's dict
+ * {prediction f32[B,L,2], target i64[B,L], seq i64[B,L], qual f32[B,L], id i64[B,256]} as `{dir}/{rank}_{index}.pt`, one
+ * file per reference batch; the consumers are `deepchopper chop` / load_predicts_from_batch_pt
+ * (src/smooth/predict.rs:264-317: candle's pickle::read_all) and torch.load.  dc_pt_* writes the same container (ZIP of
+ * STORED entries, the pickle stream torch.save emits for this dict, storages 64-byte aligned) natively on a pool of
+ * threads: torch.save's byte-wise CRC-32 and per-file Python made the wire format, not the GPU, the bound of
+ * `deepchopper predict` (754 MB/s against the 2.2 GB/s the GPU path produces on a nanopore-like length mix).
+ *
+ * dc_pt_submit queues the files of ONE fused launch and returns at once:
+ *   row0 / n_rows / col0  int32[n_files]   file i holds rows [row0, row0 + n_rows) of the launch from column col0 on
+ *                                           (the column its own left padding starts at): L = row_stride - col0
+ *   logits f32[n_total_rows][row_stride][2], labels i8[..][row_stride] (-100 = ignore), ids u8[..][row_stride] (token ids),
+ *   quals f32[..][row_stride]               the launch's dense HOST arrays -- borrowed until dc_pt_wait(ticket) returns
+ *   names / name_offsets[n_total_rows + 1], truncated u8[n_total_rows]   read ids -> the id rows [len, truncated, ord(c)...]
+ *                                           (tokenizer.py:170-175); an id longer than 127 bytes or a byte above 127 fails
+ *                                           as the reference's int8 cast does (tokenizer.py:91), DC_FQ_ERR_FORMAT
+ * dc_pt_wait(ticket) returns once every file of that submit and of all earlier ones is written (first error wins, message in
+ * dc_io_last_error); dc_pt_close waits for everything and frees the handle.  One handle per caller thread. */
+typedef struct dc_pt_writer dc_pt_writer;
+int dc_pt_open(int threads, dc_pt_writer** out);
+int dc_pt_submit(dc_pt_writer* w, const char* dir, int32_t rank, int64_t first_index, int32_t n_files, const int32_t* row0,
+                 const int32_t* n_rows, const int32_t* col0, const float* logits, const int8_t* labels, const uint8_t* ids,
+                 const float* quals, int64_t n_total_rows, int64_t row_stride, const char* names,
+                 const int64_t* name_offsets, const uint8_t* truncated, int64_t* ticket_out);
+/* The same files from payloads the GPU packed (include/deepchopper_hip.h: dc_pt_pack, copied to host memory by the caller):
+ * file i = rows [row0[i], +n_rows[i]) of the launch (for its id rows), n_cols[i] columns, its storages data/0..3 back to
+ * back at payload + payload_offset[i] (28 B per position).  Nothing is copied or converted on the host: a file goes out
+ * as one writev() of [headers | storage | header | storage ...], the CRC-32 is the only pass over the data.  `payload` is
+ * borrowed until dc_pt_wait(ticket) returns. */
+int dc_pt_submit_packed(dc_pt_writer* w, const char* dir, int32_t rank, int64_t first_index, int32_t n_files,
+                        const int32_t* row0, const int32_t* n_rows, const int32_t* n_cols, const int64_t* payload_offset,
+                        const void* payload, int64_t payload_bytes, int64_t n_total_rows, const char* names,
+                        const int64_t* name_offsets, const uint8_t* truncated, int64_t* ticket_out);
+int dc_pt_wait(dc_pt_writer* w, int64_t ticket);
+int dc_pt_close(dc_pt_writer* w);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,80 @@ def test_write_pt_batches_cuts_every_reference_batch_out_of_a_fused_launch(tmp_p
             assert int(d["id"][-1, 1]) == (1 if r0 + k == n else 0)  # the truncated flag of the last read
             assert os.path.getsize(path) < 1.2 * (k * (stride - c0) * 28) + 8192  # its own storage, not the launch's
             r0 += k
+
+
+def _fake_launch(n, stride, subs, cols, seed=0, ids_dtype="uint8"):
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    return {"logits": torch.randn(n, stride, 2, generator=g),
+            "tok": {"labels": torch.randint(-100, 2, (n, stride), dtype=torch.int8, generator=g),
+                    "input_ids": torch.randint(0, 12, (n, stride), dtype=torch.int64, generator=g).to(getattr(torch, ids_dtype)),
+                    "input_quals": torch.rand(n, stride, generator=g),
+                    "status": torch.tensor([0] * (n - 1) + [1], dtype=torch.int32)},
+            "sub_sizes": subs, "sub_cols": cols}
+
+
+def test_native_pt_writer_writes_what_torch_save_writes(tmp_path):
+    """predict.PtWriter (libdeepchopper_io: dc_pt_*) against predict.write_pt_batches (torch.save) on the same fused launch:
+    the same file names; `torch.load` gives the same keys in the same order, dtypes, shapes and values; the pickle stream inside
+    (`data.pkl`: what candle's pickle::read_all parses in the reference's chop, src/smooth/predict.rs:264-317) is byte for byte
+    torch.save's; every entry's CRC-32 checks out and every storage starts on a 64-byte boundary; a second launch continues
+    the numbering.  Batches of one row, of one column and a 70 000-column row (sizes pickled as BININT1 / BININT2 / BININT)."""
+    import zipfile
+
+    import torch
+
+    from deepchopper_amd.predict import PtWriter, write_pt_batches
+
+    launches = [(12, 2000, [5, 5, 2], [0, 600, 1250]), (4, 70001, [1, 3], [0, 70000]), (3, 300, [3], [0])]
+    first = 7
+    with PtWriter(threads=3, max_inflight=1) as w:
+        for li, (n, stride, subs, cols) in enumerate(launches):
+            res = _fake_launch(n, stride, subs, cols, seed=li, ids_dtype="uint8" if li != 2 else "int64")
+            ids = [f"read_{li}_{i}/x" for i in range(n)]
+            assert w.submit(str(tmp_path / "native"), 3, first, res, ids) == len(subs)
+            assert write_pt_batches(str(tmp_path / "torch"), 3, first, res, ids) == len(subs)
+            first += len(subs)
+    names = sorted(os.listdir(tmp_path / "torch"))
+    assert names == sorted(os.listdir(tmp_path / "native")) and len(names) == 6
+    for name in names:
+        a = torch.load(tmp_path / "torch" / name, weights_only=True)
+        b = torch.load(tmp_path / "native" / name, weights_only=True)
+        assert list(a) == list(b) == ["prediction", "target", "seq", "qual", "id"]
+        for k in a:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].stride() == b[k].stride(), (name, k)
+            assert torch.equal(a[k], b[k]), (name, k)
+        with zipfile.ZipFile(tmp_path / "torch" / name) as za, zipfile.ZipFile(tmp_path / "native" / name) as zb:
+            assert zb.testzip() is None
+            stem = name[:-3]
+            assert za.read(f"{stem}/data.pkl") == zb.read(f"{stem}/data.pkl")
+            assert [i.filename for i in za.infolist()] == [i.filename for i in zb.infolist()]
+            assert zb.read(f"{stem}/byteorder") == za.read(f"{stem}/byteorder") and zb.read(f"{stem}/version") == za.read(f"{stem}/version")
+            raw = open(tmp_path / "native" / name, "rb").read()
+            for i in zb.infolist():
+                assert i.compress_type == zipfile.ZIP_STORED
+                nlen, xlen = int.from_bytes(raw[i.header_offset + 26: i.header_offset + 28], "little"), int.from_bytes(raw[i.header_offset + 28: i.header_offset + 30], "little")
+                assert (i.header_offset + 30 + nlen + xlen) % 64 == 0, i.filename
+
+
+def test_native_pt_writer_errors(tmp_path):
+    """An id the reference's int8 cast cannot hold (tokenizer.py:91: longer than 127 characters, or a non-ASCII character)
+    fails with the reference's message at submit; an unwritable directory fails at the wait / close."""
+    import pytest
+
+    from deepchopper_amd.predict import PtWriter
+
+    res = _fake_launch(2, 50, [2], [0])
+    with PtWriter(threads=1) as w:
+        with pytest.raises(RuntimeError, match="cannot be converted to type int8"):
+            w.submit(str(tmp_path / "a"), 0, 0, res, ["ok", "x" * 128])
+        with pytest.raises(RuntimeError, match="cannot be converted to type int8"):
+            w.submit(str(tmp_path / "a"), 0, 0, res, ["ok", "naïve"])
+        assert w.submit(str(tmp_path / "a"), 0, 0, res, ["ok", "x" * 127]) == 1
+    w = PtWriter(threads=1)
+    (tmp_path / "b").mkdir()
+    (tmp_path / "b" / "0_0.pt").mkdir()  # the file's name is taken by a directory
+    w.submit(str(tmp_path / "b"), 0, 0, res, ["r0", "r1"])
+    with pytest.raises(RuntimeError, match="0_0.pt"):
+        w.close()

@@ -680,6 +680,43 @@ def test_fused_reference_batches_write_the_files_of_separate_launches(env, tmp_p
     assert np.abs(y["prediction"].numpy() - ref[ids[0]][1]).max() < 2e-4
 
 
+def test_gpu_packed_pt_files_equal_torch_save(env, tmp_path):
+    """`predict.PtWriter` on the pipeline's device tensors -- dc_pt_pack lays the storages of every reference batch of a fused
+    launch out on the GPU, one asynchronous copy brings them to pinned memory, libdeepchopper_io writes the files with a
+    writev() each -- against `write_pt_batches` (torch.save of host slices) on the same launches: same file names; `torch.load`
+    gives the same tensors bit for bit (uint8 and int64 token ids on the device alike); the pickle stream is torch.save's byte
+    for byte; CRCs check out.  Long and short reads, 31 batches over several launches, several launches in flight."""
+    import zipfile
+
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+    from deepchopper_amd.fastq import FastqReader, fuse_chunks
+    from deepchopper_amd.predict import PtWriter, write_pt_batches
+
+    seqs, quals, ids = synth.synth_reads_mixed(367, 60, 5000, seed=5)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    for ids_i64 in (False, True):
+        a, b = tmp_path / f"torch{int(ids_i64)}", tmp_path / f"packed{int(ids_i64)}"
+        n = 0
+        with FastqReader(str(fq)) as rd, PtWriter(threads=3, max_inflight=2) as w:
+            chunks = fuse_chunks(rd.chunks(12, 1 << 30), max_reads=96, max_tokens=1 << 30)
+            for res in pipe.predict_stream(chunks, reference_padding=True, ids_i64=ids_i64):
+                k = w.submit(str(b), 0, n, res["device"], res["names"], ready_event=res["ready_event"], truncated=res["truncated"])
+                assert write_pt_batches(str(a), 0, n, res["device"], res["names"]) == k
+                n += k
+        assert n == 31 and sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(b)) == 31
+        for name in sorted(os.listdir(a)):
+            x = torch.load(a / name, weights_only=True)
+            y = torch.load(b / name, weights_only=True)
+            assert list(x) == list(y)
+            for key in x:
+                assert x[key].dtype == y[key].dtype and x[key].shape == y[key].shape and torch.equal(x[key], y[key]), (name, key)
+            with zipfile.ZipFile(a / name) as za, zipfile.ZipFile(b / name) as zb:
+                assert zb.testzip() is None
+                assert za.read(name[:-3] + "/data.pkl") == zb.read(name[:-3] + "/data.pkl")
+
+
 @pytest.mark.parametrize("chop_type,ocq", [("all", False), ("terminal", False), ("internal", False), ("all", True)])
 def test_fused_predict_chop_with_reference_batching_equals_predict_then_chop(env, tmp_path, chop_type, ocq):
     """`predict --chop --reference-batching` = the reference's DEFAULT two commands -- `predict -b 12`

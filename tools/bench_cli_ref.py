@@ -27,10 +27,15 @@ save_state_dict(synthetic_state_dict(0), os.path.join(ck, "model.safetensors"))
 def run(fq: str, what: str, lens) -> dict:
     out = os.path.join(tmp, "predictions_" + what.split()[0])
     t0 = time.time()
-    p = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "predict", fq, "-o", out, "-b", "12", "-m", ck], cwd=ROOT,
-                       capture_output=True, text=True)
+    rep = os.path.join(tmp, "report.json")
+    p = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "predict", fq, "-o", out, "-b", "12", "-m", ck, "--report-json", rep],
+                       cwd=ROOT, capture_output=True, text=True)
     dt = time.time() - t0
     assert p.returncode == 0, p.stderr[-2000:]
+    with open(rep) as fh:
+        rank0 = json.load(fh)["ranks"][0]
+    phases = rank0.get("phases_s", {})
+    busy = phases.get("stream", 0) + phases.get("drain", 0)
     files = os.listdir(os.path.join(out, "0"))
     mb = sum(os.path.getsize(os.path.join(out, "0", f)) for f in files) / 1e6
     padded = sum(int(lens[i: i + 12].max() + 1) * len(lens[i: i + 12]) for i in range(0, len(lens), 12))
@@ -39,6 +44,9 @@ def run(fq: str, what: str, lens) -> dict:
             "mean_bp": round(float(lens.mean()), 1), "padded_over_real_tokens": round(padded / float(lens.sum() + len(lens)), 3),
             "seconds_whole_command": round(dt, 2), "reads_per_s": round(len(lens) / dt, 1), "Mbases_per_s": round(float(lens.sum()) / dt / 1e6, 2),
             "pt_files": len(files), "pt_MB": round(mb, 1), "pt_MB_per_s": round(mb / dt, 1),
+            "phases_s": phases, "pt_writer_main_thread_s": rank0.get("pt_writer_main_thread_s"), "reads_per_s_after_startup": round(len(lens) / busy, 1) if busy else None,
+            "pt_MB_per_s_after_startup": round(mb / busy, 1) if busy else None, "cpu_user_s": rank0.get("cpu_user_s"),
+            "cpu_sys_s": rank0.get("cpu_sys_s"), "pt_writer": os.environ.get("DC_PT_WRITER", "native"),
             "shared_prefix": os.environ.get("DC_SHARED_PREFIX", "1") != "0", "prefix_mode": os.environ.get("DC_PREFIX_MODE", "linear")}
 
 
