@@ -473,6 +473,7 @@ def main():
             if "ref" in legs:
                 configs["reference_b12"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000)
                 configs["reference_b12_nanopore"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000, mix="nanopore")
+                configs["reference_b12_nanopore_pt_files"] = leg(bench_legs.reference_b12_leg, pipe, sd, 60_000, mix="nanopore", write_pt=True)
         value = world * B * args.steps / elapsed
         print(json.dumps({
             "metric": "reads/sec through predict, 1 kb reads",

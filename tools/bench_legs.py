@@ -332,12 +332,15 @@ def file_e2e_leg(pipe, sd, n_reads: int, read_len: int, batch: int, check_reads:
 # ------------------------------------------------------------------------------------------------------------
 # the reference's default batching (-b 12)
 # ------------------------------------------------------------------------------------------------------------
-def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "uniform") -> dict:
+def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "uniform", write_pt: bool = False) -> dict:
     """FASTQ file -> batches of 12 as the reference's DataLoader forms them (deepchopper/cli.py:70) -> left-padded per batch,
     pad tokens through the model -> logits + labels + intervals on the host; reference batches share GPU
     launches (`fastq.fuse_chunks`), each with its own padding.  mix = "uniform": log-uniform lengths read_len / 2 ... 3 read_len / 2;
     "nanopore": config 5's direct-RNA-like length mix (`synth.synth_nanopore_like`: log-normal, median 900, up to 30 kb).
     `padded_over_real_tokens` = the tokens the reference's batches hold / the tokens of the reads themselves.
+    write_pt: every batch also becomes its `{rank}_{batch}.pt` (CustomWriter, callbacks.py:12-25) through predict.PtWriter -- the
+    work of `deepchopper predict reads.fq` without flags, in process (no interpreter start-up); the first file is read back with
+    torch.load and compared with the launch's logits.
     Check: the first batch against the oracle run on that batch of 12 (logits <= 1e-3, labels, intervals)."""
     import torch
 
@@ -361,11 +364,21 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
             fh.write(text)
         del text
 
+        pt_dir = os.path.join(tmp, "predictions", "0")
+        pt_stats = {}
+
         def run(limit=None):
-            n = 0
+            from deepchopper_amd.predict import PtWriter
+
+            n = n_files = 0
             first = None
+            writer = PtWriter(threads=4) if write_pt else None
             with FastqReader(path) as rd:
-                for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 2_000_000, padded=not pipe.shared_prefix), reference_padding=True, ids_i64=True):
+                for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 2_000_000, padded=not pipe.shared_prefix), reference_padding=True,
+                                               ids_i64=not write_pt):
+                    if writer is not None:
+                        n_files += writer.submit(pt_dir, 0, n_files, res["device"], res["names"], ready_event=res["ready_event"],
+                                                 truncated=res["truncated"])
                     if first is None:
                         k, c0 = res["sub_sizes"][0], res["sub_cols"][0]
                         o = res["offsets"]
@@ -375,14 +388,27 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
                     n += len(res["names"])
                     if limit and n >= limit:
                         break
+            if writer is not None:
+                writer.close()
+                pt_stats.update({"files": n_files, "main_thread_waits_s": {k: round(v, 3) for k, v in writer.timers.items()}})
             return n, first
 
         run(limit=3000)  # warm-up
+        shutil.rmtree(os.path.join(tmp, "predictions"), ignore_errors=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n, first = run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if write_pt:
+            names = os.listdir(pt_dir)
+            pt_stats["MB"] = round(sum(os.path.getsize(os.path.join(pt_dir, f)) for f in names) / 1e6, 1)
+            pt_stats["MB_per_s"] = round(pt_stats["MB"] / dt, 1)
+            d0 = torch.load(os.path.join(pt_dir, "0_0.pt"), weights_only=True)
+            pt_stats["first_file_equals_the_launch"] = bool(
+                len(names) == pt_stats["files"] and np.array_equal(d0["prediction"].numpy(), first["logits"])
+                and d0["seq"].dtype == torch.int64 and d0["target"].dtype == torch.int64 and tuple(d0["id"].shape) == (len(first["names"]), 256))
+            shutil.rmtree(os.path.join(tmp, "predictions"), ignore_errors=True)
         stage_ms = None
         if os.environ.get("DC_LEG_STAGES"):  # a second, untimed pass with the kernels bracketed by events: where the GPU time goes
             net = pipe.model.net
@@ -409,6 +435,11 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
            "shared_pad_prefix": bool(getattr(pipe, "shared_prefix", False))}
     if stage_ms is not None:
         out["stages"] = stage_ms
+    if write_pt:
+        out["workload"] = ("`deepchopper predict reads.fq` without flags, in process: FASTQ file -> the reference's batches of 12 -> one `.pt` "
+                           "per batch (CustomWriter's wire format, 28 B per padded token: storages packed on the GPU, files written by "
+                           "libdeepchopper_io) + labels + intervals")
+        out["pt"] = pt_stats
     from oracle import dc_oracle as o
     from oracle import forward_ref as fr
 

@@ -29,4 +29,6 @@ if which in ("uniform", "both"):
     out["reference_b12"] = bench_legs.reference_b12_leg(pipe, sd, n)
 if which in ("nanopore", "both"):
     out["reference_b12_nanopore"] = bench_legs.reference_b12_leg(pipe, sd, n, mix="nanopore")
+if which in ("pt", "both"):
+    out["reference_b12_nanopore_pt_files"] = bench_legs.reference_b12_leg(pipe, sd, n, mix="nanopore", write_pt=True)
 print(json.dumps(out))
