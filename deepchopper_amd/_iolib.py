@@ -40,6 +40,9 @@ _SIGNATURES = {
     "dc_pt_submit_packed": (C.c_int, [vp, C.c_char_p, C.c_int32, i64, C.c_int32, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]),
     "dc_pt_wait": (C.c_int, [vp, i64]),
     "dc_pt_close": (C.c_int, [vp]),
+    "dc_pt_load": (C.c_int, [vp, i64, C.c_int32, i64, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "dc_pt_export": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dc_pt_free": (None, [vp]),
     "dc_chop_write_chunk": (C.c_int, [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, C.c_int32, vp,
                                       C.POINTER(i64)]),
 }

@@ -112,36 +112,88 @@ def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_
          threads: int = 2, output_chopped_seqs: bool = False) -> str:
     """main() of src/bin/predict.rs:197-384.  Returns the output path
     `{prefix or fastq stem}.{n_predictions}pd.{n_records}record.chop.fq.gz` -- a BGZF stream written by
-    `threads` compression workers, as the reference's bgzf::io::MultithreadedWriter (predict.rs:266-270)."""
+    `threads` compression workers, as the reference's bgzf::io::MultithreadedWriter (predict.rs:266-270).
+
+    The predictions come out of the `.pt` files natively (`rs_api.LabelStore`: mmap + argmax + mask on a pool of threads);
+    per FASTQ chunk the reads' labels go through ONE fused GPU launch (majority vote -> regions -> filter -> complement,
+    `dc_smooth_intervals_from_labels`) and the gating / record splitting / FASTQ text / BGZF of process_chunk
+    (predict.rs:130-192) run in libdeepchopper_io (`dc_chop_write_chunk`) straight from the reader's packed chunk -- no
+    per-read Python.  Chopped records take their letters from the FASTQ record through the token alphabet (A C G T, U -> T,
+    anything else N), which is what `Predict.seq` holds when the predictions were made from this FASTQ.
+    DC_CHOP_PYTHON=1: the per-record form (`chop_chunk`, the line-by-line restatement of process_chunk)."""
     if chop_type not in CHOP_TYPES:
         raise ValueError("Invalid chop type")
     sp = sp or SmoothParams()
-    predicts: dict = {}
-    for d in predict_dirs:
-        predicts.update(rs_api.load_predicts_from_batch_pts(d, rs_api.IGNORE_LABEL, max_batch_size))
+    python_form = os.environ.get("DC_CHOP_PYTHON") == "1"
+    if python_form:
+        predicts: dict = {}
+        for d in predict_dirs:
+            predicts.update(rs_api.load_predicts_from_batch_pts(d, rs_api.IGNORE_LABEL, max_batch_size))
+        n_predictions = len(predicts)
+    else:
+        store = rs_api.LabelStore.load(predict_dirs, rs_api.IGNORE_LABEL, max_batch_size, threads=max(4, threads))
+        n_predictions = len(store)
+        params = chop_params(sp, chop_type, output_chopped_seqs)
     tmp = _temp_name(fq, output_prefix)
     n_out = n_in = 0
     try:
         with BgzfWriter(tmp, threads=threads) as fh, FastqReader(fq, full_header=True) as rd:
             for c in rd.chunks(chunk_size, 64 << 20):
                 names = c.names()
-                hdr, ho = c._names.tobytes(), c._name_offsets
-                s, q, o = c.seq.tobytes(), c.qual.tobytes(), c.offsets
-                recs = [(names[i], hdr[ho[i]: ho[i + 1]].decode("latin1"), s[o[i]: o[i + 1]], q[o[i]: o[i + 1]])
-                        for i in range(c.n)]
                 n_in += c.n
-                for rid, seq, qual in chop_chunk(recs, predicts, sp, chop_type, output_chopped_seqs):
-                    fh.write_record(rid, seq, qual)
-                    n_out += 1
+                if python_form:
+                    hdr, ho = c._names.tobytes(), c._name_offsets
+                    s, q, o = c.seq.tobytes(), c.qual.tobytes(), c.offsets
+                    recs = [(names[i], hdr[ho[i]: ho[i + 1]].decode("latin1"), s[o[i]: o[i + 1]], q[o[i]: o[i + 1]])
+                            for i in range(c.n)]
+                    for rid, seq, qual in chop_chunk(recs, predicts, sp, chop_type, output_chopped_seqs):
+                        fh.write_record(rid, seq, qual)
+                        n_out += 1
+                else:
+                    n_out += _chop_chunk_native(fh, params, sp, c, names, store)
         if n_in == 0:
             raise ValueError(f"No valid records found in {fq}")
-        final = _final_name(fq, output_prefix, len(predicts), n_out)
+        final = _final_name(fq, output_prefix, n_predictions, n_out)
         os.replace(tmp, final)
     except Exception:
         if os.path.exists(tmp):
             os.remove(tmp)
         raise
     return final
+
+
+def _chop_chunk_native(fh: BgzfWriter, params, sp: SmoothParams, c, names: list[str], store) -> int:
+    """One FASTQ chunk of `chop`: look the reads up, smooth their labels on the GPU, gate / split / write natively.  Records
+    without a prediction are skipped (predict.rs:139-142): the chunk is handled in runs of consecutive reads that have one."""
+    index = store.index
+    idx = np.fromiter((index.get(nm, -1) for nm in names), np.int64, c.n)
+    have = idx >= 0
+    if not have.any():
+        return 0
+    edges = np.flatnonzero(np.diff(np.concatenate([[False], have, [False]]).astype(np.int8)))
+    n_out = 0
+    for r0, r1 in zip(edges[0::2].tolist(), edges[1::2].tolist()):
+        ii = idx[r0:r1]
+        k = r1 - r0
+        so = store.offsets
+        lens = so[ii + 1] - so[ii]
+        slot = np.maximum(lens, 1)  # (a prediction without unmasked positions keeps a one-label slot: it passes through on its length)
+        offs = np.zeros(k + 1, np.int64)
+        np.cumsum(slot, out=offs[1:])
+        if k == int(ii[-1] - ii[0]) + 1 and bool((np.diff(ii) == 1).all()) and bool((lens > 0).all()):
+            lab = store.labels[so[ii[0]]: so[ii[-1] + 1]]  # the files follow the FASTQ's order: one slice
+        else:
+            lab = np.zeros(int(offs[-1]), np.int8)
+            for j, i in enumerate(ii.tolist()):
+                lab[offs[j]: offs[j] + lens[j]] = store.labels[so[i]: so[i + 1]]
+        res = ops.smooth_intervals_from_labels(ops.to_device(np.ascontiguousarray(lab)), ops.to_device(offs), window=sp.window,
+                                               min_interval=sp.min_interval, approved=sp.approved,
+                                               max_intervals=max(sp.approved, 1), want_smooth=False)
+        nl = c._name_len
+        n_out += fh.chop_write_chunk(params, k, c._names, c._name_offsets[r0:], None if nl is None else nl[r0:], c.seq, c.qual,
+                                     c.offsets[r0:], lens.astype(np.int32), res["n_intervals"].cpu().numpy(),
+                                     res["intervals"].cpu().numpy(), res["n_keep"].cpu().numpy(), res["keep"].cpu().numpy())
+    return n_out
 
 
 def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all", output_chopped_seqs: bool = False,

@@ -15,6 +15,8 @@
 #include "../../include/deepchopper_io.h"
 
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -23,6 +25,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <condition_variable>
 #include <cstdio>
@@ -658,6 +661,188 @@ int dc_pt_wait(dc_pt_writer* w, int64_t ticket) {
   lk.unlock();
   return rc ? dcio::fail(rc, "%s", msg.c_str()) : 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The consumer side: load_predicts_from_batch_pt(s) (src/smooth/predict.rs:211-317) for the chop driver -- every read's
+// id, truncation flag and argmax labels over its unmasked positions, straight out of the files (mmap, the ZIP central
+// directory, the storages by key), on a pool of threads.  Shapes follow from the storage sizes: id i64[B][256] gives B,
+// target i64[B][L] gives L.  A file this reader does not recognise is reported as failed and left to the caller's general
+// path (torch.load).
+// ------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct PtRows {
+  std::vector<int8_t> labels;
+  std::vector<int64_t> label_off{0};
+  std::string names;
+  std::vector<int64_t> name_off{0};
+  std::vector<uint8_t> truncated;
+  bool failed = false;
+};
+
+inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t rd16(const uint8_t* p) { return p[0] | (p[1] << 8); }
+
+bool load_one(const char* path, int64_t ignore_label, PtRows& out) {
+  const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat stt;
+  if (fstat(fd, &stt) != 0 || stt.st_size < 22) {
+    ::close(fd);
+    return false;
+  }
+  const size_t size = (size_t)stt.st_size;
+  const uint8_t* f = (const uint8_t*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (f == MAP_FAILED) return false;
+  bool ok = false;
+  do {
+    // end of central directory: the last 64 KiB + 22 bytes
+    size_t e = size - 22;
+    const size_t lo = size > 65557 ? size - 65557 : 0;
+    for (;; --e) {
+      if (rd32(f + e) == 0x06054b50u) break;
+      if (e == lo) {
+        e = (size_t)-1;
+        break;
+      }
+    }
+    if (e == (size_t)-1) break;
+    const unsigned n_entries = rd16(f + e + 10);
+    const size_t cd_size = rd32(f + e + 12), cd_off = rd32(f + e + 16);
+    if (cd_off + cd_size > size) break;
+    const uint8_t* sec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t len[5] = {0, 0, 0, 0, 0};
+    size_t p = cd_off;
+    bool bad = false;
+    for (unsigned i = 0; i < n_entries; ++i) {
+      if (p + 46 > size || rd32(f + p) != 0x02014b50u) {
+        bad = true;
+        break;
+      }
+      const unsigned method = rd16(f + p + 10), nlen = rd16(f + p + 28), xlen = rd16(f + p + 30), clen = rd16(f + p + 32);
+      const size_t csize = rd32(f + p + 20), usize = rd32(f + p + 24), lho = rd32(f + p + 42);
+      const char* name = (const char*)f + p + 46;
+      if (p + 46 + nlen > size) {
+        bad = true;
+        break;
+      }
+      // "<anything>/data/<k>", k = 0 .. 4
+      if (nlen >= 7 && name[nlen - 2] == '/' && memcmp(name + nlen - 7, "/data/", 6) == 0 && name[nlen - 1] >= '0' && name[nlen - 1] <= '4') {
+        const int k = name[nlen - 1] - '0';
+        if (method != 0 || csize != usize || csize == 0xffffffffu || lho + 30 > size || rd32(f + lho) != 0x04034b50u) {
+          bad = true;
+          break;
+        }
+        const size_t data = lho + 30 + rd16(f + lho + 26) + rd16(f + lho + 28);
+        if (data + usize > size) {
+          bad = true;
+          break;
+        }
+        sec[k] = f + data;
+        len[k] = usize;
+      }
+      p += 46 + nlen + xlen + clen;
+    }
+    if (bad || !sec[0] || !sec[1] || !sec[4] || len[4] == 0 || len[4] % 2048) break;
+    const size_t B = len[4] / 2048;
+    if (len[1] % (8 * B)) break;
+    const size_t L = len[1] / (8 * B);
+    if (L == 0 || len[0] != B * L * 8 || ((uintptr_t)sec[0] & 3) || ((uintptr_t)sec[1] & 7) || ((uintptr_t)sec[4] & 7)) break;
+    const float* logit = (const float*)sec[0];
+    const int64_t* target = (const int64_t*)sec[1];
+    const int64_t* idm = (const int64_t*)sec[4];
+    for (size_t r = 0; r < B; ++r) {
+      const int64_t* row = idm + r * 256;
+      const int64_t n = row[0];
+      if (n < 0 || n > 254) {
+        bad = true;
+        break;
+      }
+      for (int64_t c = 0; c < n; ++c) out.names.push_back((char)row[2 + c]);
+      out.name_off.push_back((int64_t)out.names.size());
+      out.truncated.push_back(row[1] != 0);
+      const float* lg = logit + r * L * 2;
+      const int64_t* tg = target + r * L;
+      for (size_t c = 0; c < L; ++c)
+        if (tg[c] != ignore_label) out.labels.push_back(lg[2 * c + 1] > lg[2 * c] ? 1 : 0);  // argmax, first maximum wins
+      out.label_off.push_back((int64_t)out.labels.size());
+    }
+    ok = !bad;
+  } while (false);
+  munmap((void*)f, size);
+  return ok;
+}
+
+}  // namespace
+
+struct dc_pt_set {
+  std::vector<PtRows> files;
+};
+
+extern "C" {
+
+int dc_pt_load(const char* const* paths, int64_t n_paths, int32_t threads, int64_t ignore_label, dc_pt_set** out, int64_t* n_reads,
+               int64_t* label_bytes, int64_t* name_bytes, int64_t* n_failed) {
+  if (!paths || n_paths < 0 || !out) return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_load: null argument");
+  auto* set = new dc_pt_set();
+  set->files.resize((size_t)n_paths);
+  std::atomic<int64_t> next{0};
+  const int nt = threads < 1 ? 1 : threads > 64 ? 64 : threads;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([&] {
+      for (;;) {
+        const int64_t i = next.fetch_add(1);
+        if (i >= n_paths) return;
+        PtRows& r = set->files[(size_t)i];
+        if (!load_one(paths[i], ignore_label, r)) {
+          r = PtRows();
+          r.failed = true;
+        }
+      }
+    });
+  for (auto& th : pool) th.join();
+  int64_t nr = 0, lb = 0, nb = 0, nf = 0;
+  for (const PtRows& r : set->files) {
+    nr += (int64_t)r.truncated.size();
+    lb += (int64_t)r.labels.size();
+    nb += (int64_t)r.names.size();
+    nf += r.failed;
+  }
+  if (n_reads) *n_reads = nr;
+  if (label_bytes) *label_bytes = lb;
+  if (name_bytes) *name_bytes = nb;
+  if (n_failed) *n_failed = nf;
+  *out = set;
+  return 0;
+}
+
+int dc_pt_export(const dc_pt_set* set, int8_t* labels, int64_t* label_offsets, char* names, int64_t* name_offsets,
+                 uint8_t* truncated, int32_t* file_of_read, uint8_t* file_failed) {
+  if (!set || !label_offsets || !name_offsets) return dcio::fail(DC_FQ_ERR_ARG, "dc_pt_export: null argument");
+  int64_t r = 0, lb = 0, nb = 0;
+  label_offsets[0] = name_offsets[0] = 0;
+  for (size_t fi = 0; fi < set->files.size(); ++fi) {
+    const PtRows& f = set->files[fi];
+    if (file_failed) file_failed[fi] = f.failed;
+    if (!f.labels.empty() && labels) memcpy(labels + lb, f.labels.data(), f.labels.size());
+    if (!f.names.empty() && names) memcpy(names + nb, f.names.data(), f.names.size());
+    for (size_t k = 0; k < f.truncated.size(); ++k, ++r) {
+      label_offsets[r + 1] = lb + f.label_off[k + 1];
+      name_offsets[r + 1] = nb + f.name_off[k + 1];
+      if (truncated) truncated[r] = f.truncated[k];
+      if (file_of_read) file_of_read[r] = (int32_t)fi;
+    }
+    lb += (int64_t)f.labels.size();
+    nb += (int64_t)f.names.size();
+  }
+  return 0;
+}
+
+void dc_pt_free(dc_pt_set* set) { delete set; }
 
 int dc_pt_close(dc_pt_writer* w) {
   if (!w) return 0;

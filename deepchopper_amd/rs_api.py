@@ -513,3 +513,73 @@ def load_predicts_from_batch_pts(pt_path, ignore_label: int = IGNORE_LABEL, max_
         except Exception as e:  # the reference prints and skips unreadable files
             print(f"load pt {f} fail caused by Error: {e!r}")
     return out
+
+
+class LabelStore:
+    """What `deepchopper chop` needs of a set of `.pt` prediction files (load_predicts_from_batch_pts,
+    src/smooth/predict.rs:211-317), packed: per read its id, truncation flag and argmax labels over its unmasked positions
+    (`Predict.prediction`; `Predict.seq_len()` = their count).  Read natively on a pool of threads (libdeepchopper_io:
+    dc_pt_load); a file that reader does not recognise goes through `load_predicts_from_batch_pt` (torch.load) instead, with
+    the reference's "load pt ... fail" line if that fails too.  `index`: id -> row, a later file winning as in the
+    reference's HashMap."""
+
+    def __init__(self, labels: np.ndarray, offsets: np.ndarray, ids: list[str], truncated: np.ndarray):
+        self.labels, self.offsets, self.ids, self.truncated = labels, offsets, ids, truncated
+        self.index = {rid: i for i, rid in enumerate(ids)}
+
+    def __len__(self) -> int:
+        return len(self.index)
+
+    def predict(self, rid: str) -> "Predict | None":
+        """The reference's `Predict` of one read (without its letters: the chop driver takes those from the FASTQ record)."""
+        i = self.index.get(rid)
+        if i is None:
+            return None
+        return Predict(self.labels[self.offsets[i]: self.offsets[i + 1]].tolist(), "", rid, bool(self.truncated[i]))
+
+    @staticmethod
+    def load(pt_paths, ignore_label: int = IGNORE_LABEL, max_predicts: int | None = None, threads: int = 4) -> "LabelStore":
+        import ctypes as C
+
+        from . import _iolib
+
+        files = []
+        for d in ([pt_paths] if isinstance(pt_paths, (str, os.PathLike)) else pt_paths):
+            found = []
+            for root, _, names in os.walk(os.fspath(d)):
+                found += [os.path.join(root, n) for n in names if n.endswith(".pt")]
+            files += found[:max_predicts] if max_predicts is not None else found
+        arr = (C.c_char_p * len(files))(*[os.fsencode(f) for f in files])
+        h = C.c_void_p()
+        n, lb, nb, nf = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _iolib.raise_for(_iolib.lib().dc_pt_load(arr, len(files), int(max(1, threads)), int(ignore_label), C.byref(h), C.byref(n),
+                                                 C.byref(lb), C.byref(nb), C.byref(nf)))
+        try:
+            labels = np.empty(lb.value, np.int8)
+            offs = np.empty(n.value + 1, np.int64)
+            names = np.empty(max(nb.value, 1), np.uint8)
+            noffs = np.empty(n.value + 1, np.int64)
+            trunc = np.empty(max(n.value, 1), np.uint8)
+            failed = np.zeros(max(len(files), 1), np.uint8)
+            _iolib.raise_for(_iolib.lib().dc_pt_export(h, labels.ctypes.data, offs.ctypes.data, names.ctypes.data, noffs.ctypes.data,
+                                                       trunc.ctypes.data, None, failed.ctypes.data))
+        finally:
+            _iolib.lib().dc_pt_free(h)
+        text = names[: nb.value].tobytes().decode("latin1")
+        ids = [text[noffs[i]: noffs[i + 1]] for i in range(n.value)]
+        trunc = trunc[: n.value].astype(bool)
+        if nf.value:  # the general path for what the native reader left alone
+            extra_l, extra_ids, extra_t = [labels], list(ids), [trunc]
+            for f in (files[i] for i in np.flatnonzero(failed[: len(files)])):
+                try:
+                    for rid, p in load_predicts_from_batch_pt(f, ignore_label).items():
+                        extra_l.append(np.asarray(p.prediction, np.int8))
+                        extra_ids.append(rid)
+                        extra_t.append(np.array([p.is_truncated]))
+                except Exception as e:  # the reference prints and skips unreadable files
+                    print(f"load pt {f} fail caused by Error: {e!r}")
+            sizes = [int(offs[-1])] + [len(x) for x in extra_l[1:]]
+            labels = np.concatenate(extra_l) if len(extra_l) > 1 else labels
+            offs = np.concatenate([offs, offs[-1] + np.cumsum(sizes[1:], dtype=np.int64)]) if len(sizes) > 1 else offs
+            ids, trunc = extra_ids, np.concatenate(extra_t)
+        return LabelStore(labels, offs, ids, trunc)

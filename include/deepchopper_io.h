@@ -196,6 +196,23 @@ int dc_pt_submit_packed(dc_pt_writer* w, const char* dir, int32_t rank, int64_t 
 int dc_pt_wait(dc_pt_writer* w, int64_t ticket);
 int dc_pt_close(dc_pt_writer* w);
 
+/* The consumer side of the wire format for the chop driver: load_predicts_from_batch_pts / _pt
+ * (src/smooth/predict.rs:211-317) over a list of `.pt` files on `threads` threads -- per read its id (the id row's
+ * [len, truncated, ord(c)...]), truncation flag and the argmax labels (first maximum wins) over the positions whose target is
+ * not `ignore_label`.  Files are read through mmap by their ZIP central directory and storage keys (`<stem>/data/0` prediction
+ * f32[B][L][2], `<stem>/data/1` target i64[B][L], `<stem>/data/4` id i64[B][256]; B and L follow from the storage sizes).  A file that
+ * is not laid out that way (or cannot be opened) is counted in n_failed and contributes no reads: the caller hands it to
+ * its general path (torch.load), which also reports the reference's "load pt ... fail" line.
+ * dc_pt_export copies the set into caller buffers sized from dc_pt_load's totals, reads in file order:
+ *   labels i8[label_bytes], label_offsets i64[n_reads + 1], names char[name_bytes], name_offsets i64[n_reads + 1],
+ *   truncated u8[n_reads], file_of_read i32[n_reads], file_failed u8[n_paths]      (any of the last three may be NULL). */
+typedef struct dc_pt_set dc_pt_set;
+int dc_pt_load(const char* const* paths, int64_t n_paths, int32_t threads, int64_t ignore_label, dc_pt_set** out,
+               int64_t* n_reads, int64_t* label_bytes, int64_t* name_bytes, int64_t* n_failed);
+int dc_pt_export(const dc_pt_set* set, int8_t* labels, int64_t* label_offsets, char* names, int64_t* name_offsets,
+                 uint8_t* truncated, int32_t* file_of_read, uint8_t* file_failed);
+void dc_pt_free(dc_pt_set* set);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,3 +311,59 @@ def test_native_pt_writer_errors(tmp_path):
     w.submit(str(tmp_path / "b"), 0, 0, res, ["r0", "r1"])
     with pytest.raises(RuntimeError, match="0_0.pt"):
         w.close()
+
+
+def test_native_pt_loader_reads_torch_save_and_native_files(tmp_path):
+    """rs_api.LabelStore.load (libdeepchopper_io: dc_pt_load) = load_predicts_from_batch_pts' argmax + mask
+    (src/smooth/predict.rs:211-317) on files torch.save wrote and on files the native writer wrote: ids, truncation flags and
+    labels equal numpy's argmax over the unmasked positions (ties -> label 0, candle's first maximum); general masks, not
+    only left padding; a file that is no `.pt` is reported in the reference's words and skipped."""
+    import numpy as np
+    import torch
+
+    from deepchopper_amd import rs_api
+    from deepchopper_amd.predict import PtWriter
+
+    rng = np.random.default_rng(3)
+    want = {}
+    d = tmp_path / "pred" / "0"
+    d.mkdir(parents=True)
+    for fi, (B, L) in enumerate([(12, 300), (1, 17), (5, 2049)]):
+        logits = rng.standard_normal((B, L, 2)).astype(np.float32)
+        logits[:, ::7, 1] = logits[:, ::7, 0]  # exact ties
+        target = np.zeros((B, L), np.int64)
+        for r in range(B):
+            p = int(rng.integers(0, L - 2))
+            target[r, :p] = -100
+            target[r, -1] = -100
+            target[r, p + int(rng.integers(0, L - p - 1))] = -100  # a masked position in the middle
+        ids = [f"read{fi}_{r}|x" for r in range(B)]
+        idm = np.zeros((B, 256), np.int64)
+        for r, s in enumerate(ids):
+            idm[r, 0], idm[r, 1] = len(s), int(r == B - 1)
+            idm[r, 2: 2 + len(s)] = [ord(c) for c in s]
+            want[s] = ((logits[r, :, 1] > logits[r, :, 0]).astype(np.int8)[target[r] != -100], r == B - 1)
+        torch.save({"prediction": torch.from_numpy(logits), "target": torch.from_numpy(target),
+                    "seq": torch.zeros(B, L, dtype=torch.int64), "qual": torch.zeros(B, L), "id": torch.from_numpy(idm)}, d / f"0_{fi}.pt")
+    # the same through the native writer (left padding only: what the pipeline produces)
+    res = _fake_launch(12, 500, [5, 7], [100, 0], seed=9)
+    res["tok"]["labels"][:] = 0
+    res["tok"]["labels"][:5, :130] = -100
+    res["tok"]["labels"][:, -1] = -100
+    names = [f"native_{i}" for i in range(12)]
+    with PtWriter(threads=2) as w:
+        w.submit(str(d), 1, 0, res, names, truncated=np.zeros(12, bool))
+    lg = res["logits"].numpy()
+    for r, s in enumerate(names):
+        c0 = 100 if r < 5 else 0
+        keep = res["tok"]["labels"][r, c0:].numpy() != -100
+        want[s] = ((lg[r, c0:, 1] > lg[r, c0:, 0]).astype(np.int8)[keep], False)
+    (d / "broken.pt").write_bytes(b"not a zip at all" * 10)
+    store = rs_api.LabelStore.load([str(tmp_path / "pred")], threads=3)
+    assert len(store) == len(want) == 30
+    for rid, (lab, trunc) in want.items():
+        i = store.index[rid]
+        assert np.array_equal(store.labels[store.offsets[i]: store.offsets[i + 1]], lab), rid
+        assert bool(store.truncated[i]) == trunc
+        p = store.predict(rid)
+        assert p.prediction == lab.tolist() and p.is_truncated == trunc

@@ -196,6 +196,42 @@ def test_chop_driver_matches_oracle(env, tmp_path):
     assert int(os.path.basename(out).split(".")[2].replace("record", "")) == len(got)
 
 
+def test_native_chop_equals_the_per_record_form(env, tmp_path, monkeypatch):
+    """`chop` (native `.pt` loader -> one GPU smoothing launch per chunk -> dc_chop_write_chunk) against its per-record form
+    (DC_CHOP_PYTHON=1: `chop_chunk`, the line-by-line restatement of process_chunk, src/bin/predict.rs:130-192) on the same
+    files, byte for byte (decompressed): `.pt` files in another order than the FASTQ, reads without a prediction (skipped,
+    predict.rs:139-142) in the middle of a chunk, short reads (passed through), small chunks, --ocq and every --ct."""
+    import gzip
+
+    torch, sd, pipe = env
+    from deepchopper_amd import synth
+    from deepchopper_amd.chop import chop
+    from deepchopper_amd.predict import PtWriter, SmoothParams
+
+    seqs, quals, ids = synth.synth_reads_mixed(90, 100, 1800, seed=11)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(synth.to_fastq(seqs, quals, ids))
+    pdir = tmp_path / "pred" / "0"
+    order = list(range(0, 90, 12))[::-1]  # batches written last to first; batch 3 (reads 36..47) has no file at all
+    with PtWriter(threads=2) as w:
+        for b, b0 in enumerate(order):
+            if b0 == 36:
+                continue
+            sl = slice(b0, b0 + 12)
+            _, res = pipe.predict_reads(ids[sl], seqs[sl], quals[sl], reference_padding=True)
+            w.submit(str(pdir), 0, b, res, ids[sl])
+    sp = SmoothParams(window=21, min_interval=5, approved=40, max_process_intervals=40)
+    for chop_type, ocq in (("all", False), ("terminal", False), ("internal", False), ("all", True)):
+        outs = {}
+        for form in ("native", "python"):
+            monkeypatch.setenv("DC_CHOP_PYTHON", "1" if form == "python" else "0")
+            out = chop([str(tmp_path / "pred")], str(fq), sp, chop_type, output_prefix=str(tmp_path / f"{form}_{chop_type}_{int(ocq)}"),
+                       chunk_size=17, output_chopped_seqs=ocq)
+            outs[form] = (os.path.basename(out).split(".", 1)[1], gzip.open(out, "rb").read())
+        assert outs["native"] == outs["python"], (chop_type, ocq)
+        assert outs["native"][0].startswith("78pd.") and outs["native"][1].count(b"\n") >= 4 * 40  # (78 of the 90 reads have a prediction)
+
+
 def test_predict_stream_matches_predict_reads(env, tmp_path):
     """FASTQ file -> native reader chunks -> predict_stream == predict_reads on the same reads (labels,
     smoothed labels, intervals, kept segments), for gzip input and ragged chunk sizes."""

@@ -39,8 +39,22 @@ def run(fq: str, what: str, lens) -> dict:
     files = os.listdir(os.path.join(out, "0"))
     mb = sum(os.path.getsize(os.path.join(out, "0", f)) for f in files) / 1e6
     padded = sum(int(lens[i: i + 12].max() + 1) * len(lens[i: i + 12]) for i in range(0, len(lens), 12))
+    # the reference's second command over those files: `deepchopper chop predictions/0 reads.fq` (src/bin/predict.rs:197-384)
+    chop_info = {}
+    if os.environ.get("DC_BENCH_CHOP", "1") != "0":
+        for form in (("native", "python") if os.environ.get("DC_BENCH_CHOP_PYTHON") == "1" else ("native",)):
+            t1 = time.time()
+            c = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "chop", os.path.join(out, "0"), fq, "-o", os.path.join(tmp, "chopped_" + form)],
+                               cwd=ROOT, capture_output=True, text=True, env={**os.environ, "DC_CHOP_PYTHON": "1" if form == "python" else "0"})
+            dtc = time.time() - t1
+            assert c.returncode == 0, c.stderr[-2000:]
+            final = c.stdout.strip().splitlines()[-1]
+            chop_info[form] = {"seconds_whole_command": round(dtc, 2), "reads_per_s": round(len(lens) / dtc, 1),
+                               "pt_MB_per_s": round(mb / dtc, 1), "output": os.path.basename(final)}
+            os.remove(final)
     subprocess.run(["rm", "-rf", out])
-    return {"command": "deepchopper predict reads.fq -b 12 (reference-compatible: .pt per batch of 12)", "input": what, "reads": len(lens),
+    return {"chop_command": chop_info or None, "two_commands_reads_per_s": round(len(lens) / (dt + chop_info["native"]["seconds_whole_command"]), 1) if chop_info else None,
+            "command": "deepchopper predict reads.fq -b 12 (reference-compatible: .pt per batch of 12)", "input": what, "reads": len(lens),
             "mean_bp": round(float(lens.mean()), 1), "padded_over_real_tokens": round(padded / float(lens.sum() + len(lens)), 3),
             "seconds_whole_command": round(dt, 2), "reads_per_s": round(len(lens) / dt, 1), "Mbases_per_s": round(float(lens.sum()) / dt / 1e6, 2),
             "pt_files": len(files), "pt_MB": round(mb, 1), "pt_MB_per_s": round(mb / dt, 1),
