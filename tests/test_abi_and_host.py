@@ -367,3 +367,39 @@ def test_native_pt_loader_reads_torch_save_and_native_files(tmp_path):
         assert bool(store.truncated[i]) == trunc
         p = store.predict(rid)
         assert p.prediction == lab.tolist() and p.is_truncated == trunc
+
+
+def test_native_pt_loader_survives_damaged_files(tmp_path):
+    """dc_pt_load on damaged `.pt` files -- truncated anywhere, bytes flipped in the ZIP structures, sizes that do not agree --
+    neither crashes nor invents reads: a file either loads with every label in {0, 1} and a plausible id, or is reported as
+    failed (and then goes to torch.load, which fails too: the reference's "load pt ... fail" line)."""
+    import numpy as np
+
+    from deepchopper_amd import rs_api
+    from deepchopper_amd.predict import PtWriter
+
+    res = _fake_launch(6, 120, [6], [0], seed=4)
+    res["tok"]["labels"][:] = 0
+    good = tmp_path / "good"
+    with PtWriter(threads=1) as w:
+        w.submit(str(good), 0, 0, res, [f"r{i}" for i in range(6)], truncated=np.zeros(6, bool))
+    raw = (good / "0_0.pt").read_bytes()
+    rng = np.random.default_rng(0)
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    cases = 0
+    for cut in (0, 10, 21, 22, 100, len(raw) // 2, len(raw) - 30, len(raw) - 1):
+        (bad / f"cut{cut}.pt").write_bytes(raw[:cut])
+        cases += 1
+    tail = len(raw) - 1400  # the central directory and the end record live here
+    for k in range(60):
+        b = bytearray(raw)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(tail, len(raw))) if k % 2 else int(rng.integers(0, len(raw)))
+            b[pos] = int(rng.integers(0, 256))
+        (bad / f"flip{k}.pt").write_bytes(bytes(b))
+        cases += 1
+    store = rs_api.LabelStore.load([str(bad)], threads=3)
+    assert len(store.ids) <= 6 * cases
+    assert store.labels.size == 0 or (set(np.unique(store.labels).tolist()) <= {0, 1})
+    assert all(len(i) <= 254 for i in store.ids)
