@@ -370,9 +370,20 @@ def reference_b12_leg(pipe, sd, n_reads: int, read_len: int = 1000, mix: str = "
         def run(limit=None):
             from deepchopper_amd.predict import PtWriter
 
+            writer = PtWriter(threads=4) if write_pt else None
+            try:
+                return _run(limit, writer)
+            except BaseException:
+                if writer is not None:
+                    try:
+                        writer.close()  # (nothing may still read the launch's pinned copies when the leg's directory goes)
+                    except Exception:
+                        pass
+                raise
+
+        def _run(limit, writer):
             n = n_files = 0
             first = None
-            writer = PtWriter(threads=4) if write_pt else None
             with FastqReader(path) as rd:
                 for res in pipe.predict_stream(fuse_chunks(rd.chunks(12, 1 << 30), 8192, 2_000_000, padded=not pipe.shared_prefix), reference_padding=True,
                                                ids_i64=not write_pt):
