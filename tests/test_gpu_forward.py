@@ -267,6 +267,37 @@ def test_gemm_modes_error_vs_float64(hip_lib):
     assert errs["bf16x6"] < 4 * max(errs["f32"], errs["oracle_f32"]) + 1e-6
 
 
+def test_long_convolution_forms_error_vs_float64(hip_lib):
+    """Which long-convolution form is nearest the truth on long reads?  Reads of 5 000 and 11 000 tokens (the 2 x 4096 and
+    3 x 4096 split transforms) through the block-Toeplitz MFMA kernel, the power-of-two FFT of rounds 2-4 and the split FFT,
+    each against a float64 evaluation of the oracle: all three within 2e-4 of it, the split form no further from it than the
+    power-of-two form (fewer passes, fewer roundings) beyond rounding noise, and the torch-fp32 oracle itself of the same size."""
+    import torch
+
+    from deepchopper_amd import ops
+    from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
+    from oracle import forward_ref as fr
+
+    sd = synthetic_state_dict(3)
+    model = ops.HipModel(sd, HyenaDNAConfig())
+    try:
+        for L in (5000, 11000):
+            rng = np.random.default_rng(L)
+            ids, q = _inputs(rng, 1, L)
+            ref64 = fr.forward(sd, ids, q, dtype=torch.float64).numpy()
+            errs = {"oracle_f32": float(np.abs(fr.forward(sd, ids, q).numpy() - ref64).max())}
+            d_ids, d_q = ops.to_device(ids.astype(np.uint8)), ops.to_device(q)
+            for name, thr, split in (("toeplitz", 1 << 20, True), ("fft_pow2", 2560, False), ("fft_split", 2560, True)):
+                model.set_fft_threshold(thr)
+                model.set_fft_split(split)
+                errs[name] = float(np.abs(model.forward(d_ids, d_q).cpu().numpy() - ref64).max())
+            print(f"L = {L}: max |logit - float64 oracle|:", {k: f"{v:.2e}" for k, v in errs.items()})
+            assert max(errs.values()) < 2e-4, errs
+            assert errs["fft_split"] < 1.5 * errs["fft_pow2"] + 2e-5, errs
+    finally:
+        model.close()
+
+
 @pytest.mark.parametrize("d_inner,gelu", [(1024, "tanh"), (512, "tanh"), (1024, "none"), (384, "tanh")])
 def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     """fp16x3: the fused MLP kernel (fc1 -> GELU -> fc2 with the hidden activation in registers, fc2's k order
