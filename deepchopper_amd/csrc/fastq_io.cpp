@@ -50,7 +50,7 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 
 namespace dcio {
-// the same thread-local message for the library's other translation units (pt_writer.cpp)
+// the same thread-local message for the library's other translation units (pt_io.cpp)
 int fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;

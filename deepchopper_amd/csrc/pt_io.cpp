@@ -1,4 +1,4 @@
-// The predict -> chop wire format written natively (include/deepchopper_io.h: dc_pt_*).
+// The predict -> chop wire format written and read natively (include/deepchopper_io.h: dc_pt_*).
 //
 // Reference behaviour restated here (never its code):
 //   CustomWriter.write_on_batch_end            deepchopper/models/callbacks.py:12-25   torch.save(prediction_dict, "{rank}_{batch}.pt")
