@@ -613,10 +613,9 @@ __device__ __forceinline__ int split_at(int k) {
 
 // Outer forward step for one n2: z[n1] = c[n2 + N2 n1] (n1 < NZ) -> the Q row entries b_k1[n2]; wf[k1] = W_M^(n2 k1), k1 >= 1
 template <int LOGN, int Q>
-__device__ __forceinline__ void split_forward_store(float2* __restrict__ s, int n2, const v2f (&z)[SplitGeo<LOGN, Q>::NZ],
-                                                    const float2 (&wf)[Q]) {
+__device__ __forceinline__ void split_forward_store(float2* __restrict__ col, const v2f (&z)[SplitGeo<LOGN, Q>::NZ],
+                                                    const float2 (&wf)[Q]) {  // col = row 0's slot of n2
   using G = SplitGeo<LOGN, Q>;
-  float2* const col = s + pad16(n2);
 #pragma unroll
   for (int k1 = 0; k1 < Q; ++k1) {
     v2f acc = z[0];
@@ -651,7 +650,7 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16) void hyena_fftq_filter_kernel
     }
 #pragma unroll
     for (int k1 = 1; k1 < Q; ++k1) wf[k1] = twq[2 * n2 * k1 * qstep];
-    split_forward_store<LOGN, Q>(s, n2, z, wf);
+    split_forward_store<LOGN, Q>(s + pad16(n2), z, wf);
   }
   __syncthreads();
   const int grp = tid / TG;
@@ -791,12 +790,15 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
   __syncthreads();
 
   // ---- outer forward step -> rows ----
+  // (T is a multiple of 16: the padded slot of n2 = tid + j T is that of tid plus j (T + T / 16) -- one address, constant offsets)
+  constexpr int PSTEP = T + T / 16;
+  float2* const s_me = s + pad16(tid);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n2 = tid + j * T;
     if (Q == 1) {
-      s[pad16(n2)] = F(z[j][0]);
-      s[pad16(n2 + N2 / 2)] = make_float2(0.f, 0.f);
+      s_me[j * PSTEP] = F(z[j][0]);
+      s_me[j * PSTEP + (N2 / 2 + N2 / 32)] = make_float2(0.f, 0.f);
     } else if ((16 % Q) == 0 || n2 < N2) {
       float2 wf[Q];
 #pragma unroll
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
         const int e = (j * k1) & 15;
         wf[k1] = e == 0 ? wb[k1] : cmul(wb[k1], unit_root(e, 16));
       }
-      split_forward_store<LOGN, Q>(s, n2, z[j], wf);
+      split_forward_store<LOGN, Q>(s_me + j * PSTEP, z[j], wf);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -814,8 +816,14 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
 
   // ---- spectrum product and repacking for the inverse transform (stored conjugated: IFFT = conj . FFT . conj) ----
   const float2* K = spec + (int64_t)c * (M + 1);
-  auto product = [&](int kk, float2 kf_, float2 kb_, float2 wk_) {  // kf = K[kk], kb = K[M - kk], wk = W_2M^kk
-    float2* const pk = s + split_at<LOGN, Q>(kk);
+  // Bin kk_j = tid + j T lives in row kk mod Q = tid mod Q (T is a multiple of Q) at index kk / Q = tid / Q + j T / Q, and
+  // T / Q = N2 / 16 is a multiple of 16: its padded slot is that of tid plus j (T / Q) 17 / 16, its partner's (M - kk_j) that of
+  // M - tid minus the same -- two addresses per thread, constant offsets
+  constexpr int KSTEP = T / Q + T / Q / 16;
+  static_assert(T % Q == 0 && (T / Q) % 16 == 0, "bin slots by constant strides");
+  float2* const pk0 = s + split_at<LOGN, Q>(tid);
+  float2* const pmk0 = s + split_at<LOGN, Q>(M - tid);  // (thread 0: bin M, one slot behind row 0 -- never dereferenced, see product)
+  auto product = [&](int kk, float2* pk, float2* pmk, float2 kf_, float2 kb_, float2 wk_) {  // kf = K[kk], kb = K[M - kk], wk = W_2M^kk
     const v2f ck = V(*pk);
     const v2f kf = V(kf_), kb = V(kb_), wk = V(wk_);
     if (kk == 0) {
@@ -824,7 +832,6 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
       *pk = make_float2(0.5f * (y0 + ym), -0.5f * (y0 - ym));
       return;
     }
-    float2* const pmk = s + split_at<LOGN, Q>(M - kk);
     const v2f cmk = V(*pmk);
     const v2f half = 0.5f;
     const v2f bc = vconj(cmk);
@@ -857,10 +864,10 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
       constexpr float C32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
                                 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
       const float2 wk = j == 0 ? wk0 : cmul(wk0, make_float2(C32[j], -C32[8 - j]));  // exp(-2 pi i j / 32)
-      product(tid + j * T, kf[j], kb[j], wk);
+      product(tid + j * T, pk0 + j * KSTEP, pmk0 - j * KSTEP, kf[j], kb[j], wk);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (tid == 0) product(M / 2, km, km, wm);  // the self-paired middle bin
+    if (tid == 0) product(M / 2, s + split_at<LOGN, Q>(M / 2), s + split_at<LOGN, Q>(M / 2), km, km, wm);  // the self-paired middle bin
   }
   __syncthreads();
 
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
   for (int j = 0; j < NJ; ++j) {
     const int b = tid + j * T;
     if (Q != 1 && (16 % Q) != 0 && b >= N2) continue;
-    const float2* const col = s + pad16(b);
+    const float2* const col = s_me + j * PSTEP;
     v2f tk[Q];
     tk[0] = V(col[0]);
 #pragma unroll
