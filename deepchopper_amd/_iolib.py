@@ -35,6 +35,7 @@ _SIGNATURES = {
     "dc_bgzf_mark": (C.c_int, [vp]),
     "dc_bgzf_mark_count": (C.c_int64, [vp]),
     "dc_bgzf_close2": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "dc_deflate_block": (C.c_int, [vp, i64, vp, i64, C.POINTER(i64)]),
     "dc_pt_open": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "dc_pt_submit": (C.c_int, [vp, C.c_char_p, C.c_int32, i64, C.c_int32, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]),
     "dc_pt_submit_packed": (C.c_int, [vp, C.c_char_p, C.c_int32, i64, C.c_int32, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, C.POINTER(i64)]),

@@ -123,6 +123,14 @@ int64_t dc_bgzf_mark_count(const dc_bgzf_writer* w);
 int dc_bgzf_close2(dc_bgzf_writer* w, int64_t* mark_offsets, int64_t cap, int64_t* n_marks, int64_t* data_bytes,
                    double* deflate_cpu_seconds);
 
+/* Raw DEFLATE (RFC 1951) of one block of fewer than 65 535 bytes by this library's own encoder (csrc/fast_deflate.h) -- what
+ * dc_bgzf_* puts inside every BGZF block at the default level 6 (noodles / flate2's default in the reference's writer,
+ * src/output/writefq.rs:252-276): zlib level 6's ratio on nanopore FASTQ at 2.5 times its speed (two match finders, matches
+ * taken only where they are cheaper than their literals, one dynamic-Huffman block; a stored block if that is smaller).
+ * Deterministic: the same bytes for the same input, whatever ran before.  Returns DC_FQ_ERR_ARG if `cap` is too small
+ * (n + 5 always suffices). */
+int dc_deflate_block(const uint8_t* in, int64_t n, uint8_t* out, int64_t cap, int64_t* out_len);
+
 /* ---- chop stage of the fused predict -> chop flow ------------------------------------------------
  * One call per reader chunk: the gating of process_chunk (src/bin/predict.rs:130-192), the record
  * splitting of split_noodle_records_by_remove_intervals (src/output/split.rs:171-226) or, with
