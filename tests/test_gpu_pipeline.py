@@ -716,6 +716,49 @@ def test_fused_reference_batches_write_the_files_of_separate_launches(env, tmp_p
     assert np.abs(y["prediction"].numpy() - ref[ids[0]][1]).max() < 2e-4
 
 
+def test_pt_pack_against_numpy_on_random_geometries(env):
+    """dc_pt_pack alone: random launches ([n, stride] dense arrays), random files (any rows, any first column, gaps and
+    overlaps between files allowed), uint8 and int64 token ids -- every file's payload is prediction f32[B][L][2] | target
+    i64[B][L] | seq i64[B][L] | qual f32[B][L] of its slice, bit for bit; bytes between payloads are left alone; bad tables
+    (rows outside the launch, unaligned or overflowing offsets) are refused."""
+    torch, sd, pipe = env
+    from deepchopper_amd import _lib, ops
+
+    rng = np.random.default_rng(12)
+    for trial in range(8):
+        n, stride = int(rng.integers(1, 40)), int(rng.integers(1, 3000))
+        logits = rng.standard_normal((n, stride, 2)).astype(np.float32)
+        labels = rng.integers(-100, 2, (n, stride)).astype(np.int8)
+        ids = rng.integers(0, 12, (n, stride)).astype(np.int64 if trial % 2 else np.uint8)
+        quals = rng.random((n, stride)).astype(np.float32)
+        files, off = [], 0
+        for _ in range(int(rng.integers(1, 12))):
+            r0 = int(rng.integers(0, n))
+            B = int(rng.integers(1, n - r0 + 1))
+            c0 = int(rng.integers(0, stride))
+            off = (off + 63) // 64 * 64 + 64 * int(rng.integers(0, 3))
+            files.append((r0, B, c0, off))
+            off += B * (stride - c0) * 28
+        table = np.array(files, np.int64)
+        out = torch.full((off + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+        ops.pt_pack(ops.to_device(logits), ops.to_device(labels), ops.to_device(ids), ops.to_device(quals), table, out)
+        got = out.cpu().numpy()
+        want = np.full(off + 64, 0xAB, np.uint8)
+        for r0, B, c0, o in files:
+            L = stride - c0
+            parts = [logits[r0: r0 + B, c0:].tobytes(), labels[r0: r0 + B, c0:].astype(np.int64).tobytes(),
+                     ids[r0: r0 + B, c0:].astype(np.int64).tobytes(), quals[r0: r0 + B, c0:].tobytes()]
+            blob = np.frombuffer(b"".join(parts), np.uint8)
+            assert blob.size == B * L * 28
+            want[o: o + blob.size] = blob
+        assert np.array_equal(got, want), trial
+    d = [ops.to_device(logits), ops.to_device(labels), ops.to_device(ids), ops.to_device(quals)]
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    for bad in ([[0, n + 1, 0, 0]], [[0, 1, stride, 0]], [[0, 1, 0, 32]], [[0, n, 0, (1 << 20) - 64]], [[-1, 1, 0, 0]]):
+        with pytest.raises(_lib.DeepChopperHipError):
+            ops.pt_pack(*d, np.array(bad, np.int64), out)
+
+
 def test_gpu_packed_pt_files_equal_torch_save(env, tmp_path):
     """`predict.PtWriter` on the pipeline's device tensors -- dc_pt_pack lays the storages of every reference batch of a fused
     launch out on the GPU, one asynchronous copy brings them to pinned memory, libdeepchopper_io writes the files with a
