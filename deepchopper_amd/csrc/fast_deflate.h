@@ -35,9 +35,11 @@ constexpr int kNice = 64;        // ... and ends the search
 // what a match costs: the length symbol and the distance symbol of a block that uses many matches (4 and 3 bits, measured on
 // nanopore FASTQ) + their extra bits
 constexpr float kLenBits = 4.0f, kDistBits = 3.0f, kGainMin = 0.0f, kLazyFrac = 1.0f;
+constexpr int kColdAfter = 24, kColdDepth = 3, kGoodLen = 8;
 #else
 static int kHashBytes = 4, kChainDepth = 12, kLazyBelow = 48, kNice = 64;
 static float kLenBits = 4.0f, kDistBits = 3.0f, kGainMin = 0.0f, kLazyFrac = 1.0f;
+static int kColdAfter = 24, kColdDepth = 3, kGoodLen = 8;
 #endif
 
 struct Workspace {
@@ -277,7 +279,7 @@ static size_t compress_block(const uint8_t* in, size_t n, uint8_t* out, size_t c
     int len, dist;
     float gain;
   };
-  auto find = [&](size_t i) -> M {
+  auto find = [&](size_t i, int depth) -> M {
     M best{0, 0, kGainMin};
     if (i > hash_end) return best;
     const int max = (int)std::min<size_t>(kMaxMatch, n - i);
@@ -302,16 +304,22 @@ static size_t compress_block(const uint8_t* in, size_t n, uint8_t* out, size_t c
       const float gain = cum[l] - match_cost(l, dist);
       if (gain > best.gain) best = {l, dist, gain};
     };
-    if (const uint32_t c8 = w.head8[hash8(in + i)]) {
+    const uint32_t h8 = hash8(in + i), h4 = hash4(in + i);
+    if (const uint32_t c8 = w.head8[h8]) {
       if (i - (c8 - 1) <= (size_t)kMaxDist) consider(c8 - 1);
     }
-    uint32_t c = w.head4[hash4(in + i)];
-    for (int d = 0; c && d < kChainDepth && longest < kNice; ++d) {
+    const uint32_t first = w.head4[h4];
+    uint32_t c = first;
+    for (int d = 0; c && d < depth && longest < kNice; ++d) {
       const size_t cp = c - 1;
       if (i - cp > (size_t)kMaxDist) break;
       consider(cp);
       c = w.prev4[cp];
     }
+    // ... and position i becomes a candidate itself (its hashes are at hand)
+    w.prev4[i] = (uint16_t)first;
+    w.head4[h4] = (uint16_t)(i + 1);
+    w.head8[h8] = (uint16_t)(i + 1);
     return best;
   };
   auto insert = [&](size_t i) {
@@ -322,14 +330,19 @@ static size_t compress_block(const uint8_t* in, size_t n, uint8_t* out, size_t c
     w.head8[hash8(in + i)] = (uint16_t)(i + 1);
   };
 
+  // Search effort follows the text: inside a stretch that has not produced a match for a while (a sequence line: its 4-mers
+  // have all been seen, none of the finds pays) the chains are walked kColdDepth deep; a match brings the full depth back.  The
+  // lazy second look behind a match that is already long gets a quarter of the depth, as zlib's good_length does.
+  int cold = 0;
+  auto depth_now = [&]() { return cold > kColdAfter ? kColdDepth : kChainDepth; };
   size_t i = 0;
-  M cur = find(0);
+  M cur = find(0, kChainDepth);
   while (i < n) {
     if (cur.len >= kHashBytes && cur.gain > kGainMin) {
+      cold = 0;
       // one step of lazy evaluation: a better match one byte on wins over this one + makes this byte a literal
       if (cur.len < kLazyBelow && i + 1 < n) {
-        insert(i);
-        const M nxt = find(i + 1);
+        const M nxt = find(i + 1, cur.len >= kGoodLen ? std::max(1, kChainDepth / 4) : kChainDepth);
         if (nxt.len >= kHashBytes && nxt.gain > cur.gain + w.lit_cost[in[i]] * kLazyFrac) {
           syms[ns++] = in[i];
           ++i;
@@ -337,18 +350,18 @@ static size_t compress_block(const uint8_t* in, size_t n, uint8_t* out, size_t c
           continue;
         }
         syms[ns++] = 0x80000000u | (uint32_t)(cur.len - 3) << 16 | (uint32_t)(cur.dist - 1);
-        for (size_t k = i + 1; k < i + (size_t)cur.len; ++k) insert(k);
+        for (size_t k = i + 2; k < i + (size_t)cur.len; ++k) insert(k);  // (i and i + 1 went in with their searches)
       } else {
         syms[ns++] = 0x80000000u | (uint32_t)(cur.len - 3) << 16 | (uint32_t)(cur.dist - 1);
-        for (size_t k = i; k < i + (size_t)cur.len; ++k) insert(k);
+        for (size_t k = i + 1; k < i + (size_t)cur.len; ++k) insert(k);
       }
       i += (size_t)cur.len;
-      cur = i < n ? find(i) : M{0, 0, 0.f};
+      cur = i < n ? find(i, kChainDepth) : M{0, 0, 0.f};
     } else {
       syms[ns++] = in[i];
-      insert(i);
       ++i;
-      cur = i < n ? find(i) : M{0, 0, 0.f};
+      ++cold;
+      cur = i < n ? find(i, depth_now()) : M{0, 0, 0.f};
     }
   }
 
