@@ -571,8 +571,9 @@ struct GateSrc {
 // (two workgroups per CU, 8 dependent global round trips of ~3 us each in the round-2 form): the channel's x1 | v rows are
 // staged in the transform's own LDS with 16-byte loads, all in flight at once; the spectrum loads of the product phase and
 // the output gate's loads are each one batch; the twiddles of the outer steps and of the product phase are one table look-up
-// per thread times compile-time roots of unity.  Measured on the config-4 length mix (profiles/r05b_*): 2^13 class 2.16 ->
-// 0.70 + (the 6 144-point class, dropped: 1.04) ms per launch; FFT stage -25 %.  Size classes that were built and measured
+// per thread times compile-time roots of unity.  Measured on the config-4 length mix, per launch of a non-table layer
+// (profiles/r05b_rocprofv3_kernel_stats_config4_mixed.csv): 2^13 class 2.16 -> 1.58 ms, 2^14 class 1.39 -> 0.95 ms (as
+// 3 x 4096), 2^12 class 0.63 -> 0.50 ms (the one-row form); FFT stage -27 %.  Size classes that were built and measured
 // and did NOT pay -- 3 x 1024, 3 x 2048, 5 x 2048 points: fewer points, but 3 / 6 / 10 waves per workgroup fill a CU worse
 // than 8 / 12 / 16 -- are not instantiated (profiles/r05b_fft_class_sweep.jsonl).
 // W_M / W_2M come from `twq` (W_2M^n = twq[n * qstep]: the 2^16 table for Q = 1, 2, 4; the 24 576-th roots for Q = 3), the
