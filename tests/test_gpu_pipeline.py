@@ -209,6 +209,8 @@ def test_native_chop_equals_the_per_record_form(env, tmp_path, monkeypatch):
     from deepchopper_amd.predict import PtWriter, SmoothParams
 
     seqs, quals, ids = synth.synth_reads_mixed(90, 100, 1800, seed=11)
+    long_s, long_q, long_i = synth.synth_reads_fixed(1, 33500, seed=3, start_index=7000)  # longer than the model's context: its
+    seqs[5], quals[5], ids[5] = long_s[0].tobytes(), long_q[0].tobytes(), long_i[0]      # prediction is truncated -> passes through
     fq = tmp_path / "reads.fq"
     fq.write_bytes(synth.to_fastq(seqs, quals, ids))
     pdir = tmp_path / "pred" / "0"
@@ -229,6 +231,7 @@ def test_native_chop_equals_the_per_record_form(env, tmp_path, monkeypatch):
                        chunk_size=17, output_chopped_seqs=ocq)
             outs[form] = (os.path.basename(out).split(".", 1)[1], gzip.open(out, "rb").read())
         assert outs["native"] == outs["python"], (chop_type, ocq)
+        assert b"@" + ids[5].encode() + b"\n" + seqs[5] + b"\n" in outs["native"][1]  # the truncated read: as read
         assert outs["native"][0].startswith("78pd.") and outs["native"][1].count(b"\n") >= 4 * 40  # (78 of the 90 reads have a prediction)
 
 
