@@ -112,3 +112,28 @@ def test_bad_arguments():
     buf = (C.c_ubyte * 100).from_buffer_copy(np.random.default_rng(0).integers(0, 256, 100, dtype=np.uint8).tobytes())
     assert _iolib.lib().dc_deflate_block(buf, 100, out, 16, C.byref(n)) != 0      # incompressible: no room for the stored block
     assert _iolib.lib().dc_deflate_block(buf, 70000, out, 16, C.byref(n)) != 0    # a block is < 65 535 bytes
+
+
+def test_round_trip_property():
+    """hypothesis: any byte string a BGZF payload can be -- drawn to provoke the encoder's corners (tiny alphabets, runs, repeats
+    at every distance, text next to noise) -- comes back from zlib's inflater unchanged, never larger than a stored block."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    chunk = st.one_of(
+        st.binary(min_size=0, max_size=300),
+        st.builds(lambda b, k: bytes([b]) * k, st.integers(0, 255), st.integers(1, 3000)),
+        st.builds(lambda s, k: s * k, st.binary(min_size=1, max_size=40), st.integers(1, 400)),
+        st.builds(lambda k, seed: np.random.default_rng(seed).choice(list(b"ACGT"), k).astype(np.uint8).tobytes(), st.integers(1, 4000), st.integers(0, 1 << 30)),
+        st.text(alphabet="@:= abcdefghijklmnopqrstuvwxyz0123456789-_\n", min_size=0, max_size=400).map(str.encode),
+    )
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.lists(chunk, min_size=0, max_size=30))
+    def check(parts):
+        data = b"".join(parts)[:65534]
+        raw = deflate(data)
+        assert inflate(raw) == data
+        assert len(raw) <= len(data) + 5
+
+    check()
