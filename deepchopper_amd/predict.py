@@ -643,3 +643,9 @@ class PtWriter:
 
     def __exit__(self, *exc):
         self.close()
+
+    def __del__(self):  # a writer dropped without close(): finish what was queued, quietly
+        try:
+            self.close()
+        except Exception:
+            pass
