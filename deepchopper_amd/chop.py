@@ -137,7 +137,7 @@ def chop(predict_dirs: list[str], fq: str, sp: SmoothParams | None = None, chop_
     tmp = _temp_name(fq, output_prefix)
     n_out = n_in = 0
     try:
-        with BgzfWriter(tmp, threads=threads) as fh, FastqReader(fq, full_header=True) as rd:
+        with BgzfWriter(tmp, threads=threads) as fh, FastqReader(fq, full_header=True, strict_four_line=True) as rd:
             for c in rd.chunks(chunk_size, 64 << 20):
                 names = c.names()
                 n_in += c.n
@@ -257,7 +257,7 @@ def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | Non
                 return fuse_chunks(src, max_reads, max_tokens, padded=not getattr(pipe, "shared_prefix", False))
 
             if chunks is None:
-                with FastqReader(fq, full_header=True) as rd:
+                with FastqReader(fq, full_header=True, strict_four_line=True) as rd:
                     src = rd.chunks(reference_batch, 1 << 30) if ref else rd.chunks(max_reads, max_tokens)
                     n_reads, n_out = predict_chop_stream(pipe, batches(src), fh, chop_type, output_chopped_seqs,
                                                          reference_padding=ref, mark_sub_batches=mark_sub_batches)

@@ -751,6 +751,7 @@ struct dc_fq_reader {
   int64_t range_begin = 0, range_end = INT64_MAX;
   int64_t n_records = 0;
   bool finished = false;
+  bool strict4 = false;  // dc_fq_set_strict: records are exactly four lines (the reference's chop reads with noodles)
 
   int64_t range_limit() const { return src.compressed ? src.range_end_u.load() : range_end; }
 
@@ -912,6 +913,11 @@ int dc_fq_open_range(const char* path, int64_t byte_begin, int64_t byte_end, int
 }
 
 int64_t dc_fq_records_read(const dc_fq_reader* r) { return r ? r->n_records : 0; }
+int dc_fq_set_strict(dc_fq_reader* r, int strict_four_line) {
+  if (!r) return fail(DC_FQ_ERR_ARG, "dc_fq_set_strict: null reader");
+  r->strict4 = strict_four_line != 0;
+  return 0;
+}
 int64_t dc_fq_bytes_consumed(const dc_fq_reader* r) { return r ? r->src.consumed.load() : 0; }
 void dc_fq_close(dc_fq_reader* r) { delete r; }
 
@@ -960,7 +966,7 @@ static int read_chunk_impl(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uin
     //  with a wrapped quality.  If that does not add up exactly, the record is judged as the 4-line record it looks like.)
     const bool sep3 = ok && r->buf[e[1] + 1] == '+';
     auto bare = [&](size_t a, size_t b) { while (b > a && r->buf[b - 1] == '\r') --b; return b - a; };
-    if (ok && r->buf[r->pos] == '@' && (!sep3 || bare(e[2] + 1, e[3]) < bare(e[0] + 1, e[1]))) {
+    if (!r->strict4 && ok && r->buf[r->pos] == '@' && (!sep3 || bare(e[2] + 1, e[3]) < bare(e[0] + 1, e[1]))) {
       const size_t e3_four_line = e[3];
       if (r->ranged && sep3) goto four_line;
       if (r->ranged)

@@ -211,8 +211,9 @@ std::vector<uint8_t> make_pickle(int64_t B, int64_t L) {
 // Folding as in Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ" (Intel, 2009): four 128-bit
 // lanes are multiplied by x^(512 +- 32) mod P and xored into the next 64 bytes, then folded to one lane (x^(128 +- 32)),
 // to 64 bits and reduced (Barrett).  Constants for the reflected polynomial.  zlib 1.2.11's table CRC runs at ~1 GB/s and was
-// the largest share of a file's cost; this one at > 10 GB/s.  Checked against zlib's on first use (and on every file's
-// pickle stream); a CPU without PCLMULQDQ or a mismatch keeps zlib's.
+// the largest share of a file's cost; this one at > 10 GB/s.  Checked against zlib's on first use (every length remainder x
+// every pointer misalignment) and on every file's small entries (`Zip::small`: data.pkl, byteorder, version); a CPU without
+// PCLMULQDQ or any mismatch keeps zlib's.
 #if defined(__x86_64__)
 __attribute__((target("pclmul,sse4.1"))) inline __m128i crc_fold(__m128i x, __m128i k, __m128i next) {
   return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), next);
@@ -251,18 +252,31 @@ __attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t crc0, con
 }
 #endif
 
+// Cleared when the carry-less CRC ever disagrees with zlib's (the self-test below, or the cross-check `small()` makes on every
+// small ZIP entry, data.pkl among them): from then on every CRC of the process is zlib's.
+std::atomic<bool> g_clmul_ok{true};
+
 uint32_t crc32_fast(const uint8_t* p, size_t n) {
 #if defined(__x86_64__)
   static const bool ok = [] {
     if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
-    uint8_t t[4096 + 48];
+    // every length remainder mod 64 (the fold loop's tail, the 16-byte steps, zlib's byte tail) at every pointer
+    // misalignment mod 16, and two long runs
+    static uint8_t t[8192 + 64];
     uint32_t x = 12345;
     for (auto& v : t) v = (uint8_t)((x = x * 1664525u + 1013904223u) >> 24);
-    for (size_t len : {(size_t)64, (size_t)80, (size_t)1024, (size_t)4096 + 48})
-      if (crc32_clmul(0, t, len) != (uint32_t)crc32_z(0L, t, len)) return false;
-    return true;
+    auto both = [&](const uint8_t* q, size_t len) {
+      const size_t body = len & ~(size_t)15;
+      uint32_t c = crc32_clmul(0, q, body);
+      if (body != len) c = (uint32_t)crc32_z(c, q + body, len - body);
+      return c == (uint32_t)crc32_z(0L, q, len);
+    };
+    for (size_t off = 0; off < 16; ++off)
+      for (size_t len = 64; len < 64 + 130; ++len)
+        if (!both(t + off, len)) return false;
+    return both(t + 3, 4096 + 48) && both(t, 8192 + 61);
   }();
-  if (ok && n >= 64) {
+  if (ok && n >= 64 && g_clmul_ok.load(std::memory_order_relaxed)) {
     const size_t body = n & ~(size_t)15;
     const uint32_t c = crc32_clmul(0, p, body);
     return body == n ? c : (uint32_t)crc32_z(c, p + body, n - body);
@@ -327,7 +341,11 @@ struct Zip {
     pos += 30 + name.size() + extra;
   }
   void small(const std::string& name, const void* p, size_t n) {
-    header(name, n, crc32_fast((const uint8_t*)p, n));
+    // (a few hundred bytes: both CRCs, every file -- a length-specific fault of the fast one would otherwise write entries
+    //  torch.load's and the reference's readers reject)
+    const uint32_t slow = (uint32_t)crc32_z(0L, (const uint8_t*)p, n);
+    if (crc32_fast((const uint8_t*)p, n) != slow) g_clmul_ok.store(false, std::memory_order_relaxed);
+    header(name, n, slow);
     meta.raw(p, n);
     pos += n;
   }
@@ -685,6 +703,290 @@ struct PtRows {
 inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint32_t rd16(const uint8_t* p) { return p[0] | (p[1] << 8); }
 
+// ---- data.pkl: the subset of pickle protocol 2 torch.save emits for a dict of tensors ------------------------------
+// (what candle_core::pickle::read_all interprets for the reference, src/smooth/predict.rs:268.)  A small stack machine:
+// strings, integers, tuples, globals, the persistent-id storage tuple and the `_rebuild_tensor_v2` REDUCE.  Anything else --
+// an opcode, a global or a shape this reader does not know -- makes the file "not recognised" and the caller's
+// torch.load route takes it; nothing is guessed from byte sizes.
+struct PtTensor {
+  int dtype = -1;  // index into kStorage
+  std::string key;  // storage entry "<stem>/data/<key>"
+  int64_t storage_numel = 0, offset = 0;
+  std::vector<int64_t> shape, stride;
+};
+struct StorageKind {
+  const char* name;
+  int width;
+};
+const StorageKind kStorage[] = {{"FloatStorage", 4}, {"LongStorage", 8}, {"CharStorage", 1}, {"IntStorage", 4},
+                                {"ShortStorage", 2}, {"ByteStorage", 1}, {"DoubleStorage", 8}, {"BoolStorage", 1}};
+enum { ST_FLOAT = 0, ST_LONG, ST_CHAR, ST_INT, ST_SHORT, ST_BYTE, ST_DOUBLE, ST_BOOL };
+
+struct PVal {
+  enum Kind { NONE, MARK, INT, STR, GLOBAL, TUPLE, STORAGE, TENSOR, DICT, BOOL, OPAQUE } kind = NONE;
+  int64_t i = 0;
+  std::string s;            // STR; GLOBAL "module name"
+  std::vector<PVal> items;  // TUPLE; DICT (key, value, key, value ...)
+  PtTensor t;               // STORAGE (dtype, key, numel) / TENSOR
+};
+
+bool parse_pickle(const uint8_t* p, size_t n, std::vector<std::pair<std::string, PtTensor>>& out) {
+  std::vector<PVal> st;
+  std::vector<PVal> memo;
+  size_t i = 0;
+  auto need = [&](size_t k) { return i + k <= n; };
+  auto pop_to_mark = [&](std::vector<PVal>& items) {
+    size_t m = st.size();
+    while (m > 0 && st[m - 1].kind != PVal::MARK) --m;
+    if (m == 0) return false;
+    items.assign(std::make_move_iterator(st.begin() + (long)m), std::make_move_iterator(st.end()));
+    st.resize(m - 1);
+    return true;
+  };
+  auto set_memo = [&](size_t k) {
+    if (st.empty() || k > 65536) return false;
+    if (memo.size() <= k) memo.resize(k + 1);
+    memo[k] = st.back();
+    return true;
+  };
+  auto tuple_of = [&](size_t k) {
+    if (st.size() < k) return false;
+    PVal t;
+    t.kind = PVal::TUPLE;
+    t.items.assign(std::make_move_iterator(st.end() - (long)k), std::make_move_iterator(st.end()));
+    st.resize(st.size() - k);
+    st.push_back(std::move(t));
+    return true;
+  };
+  auto ints = [](const PVal& v, std::vector<int64_t>& o) {
+    if (v.kind != PVal::TUPLE) return false;
+    for (const PVal& x : v.items) {
+      if (x.kind != PVal::INT) return false;
+      o.push_back(x.i);
+    }
+    return true;
+  };
+  while (i < n) {
+    const uint8_t op = p[i++];
+    PVal v;
+    switch (op) {
+      case 0x80:  // PROTO
+        if (!need(1) || p[i] < 2 || p[i] > 5) return false;
+        ++i;
+        break;
+      case '}':
+        v.kind = PVal::DICT;
+        st.push_back(std::move(v));
+        break;
+      case ')':
+        v.kind = PVal::TUPLE;
+        st.push_back(std::move(v));
+        break;
+      case '(':
+        v.kind = PVal::MARK;
+        st.push_back(std::move(v));
+        break;
+      case 'N':
+        st.push_back(std::move(v));
+        break;
+      case 0x88:
+      case 0x89:
+        v.kind = PVal::BOOL;
+        v.i = op == 0x88;
+        st.push_back(std::move(v));
+        break;
+      case 'K':
+        if (!need(1)) return false;
+        v.kind = PVal::INT;
+        v.i = p[i];
+        i += 1;
+        st.push_back(std::move(v));
+        break;
+      case 'M':
+        if (!need(2)) return false;
+        v.kind = PVal::INT;
+        v.i = rd16(p + i);
+        i += 2;
+        st.push_back(std::move(v));
+        break;
+      case 'J':
+        if (!need(4)) return false;
+        v.kind = PVal::INT;
+        v.i = (int32_t)rd32(p + i);
+        i += 4;
+        st.push_back(std::move(v));
+        break;
+      case 0x8a: {  // LONG1
+        if (!need(1)) return false;
+        const unsigned k = p[i++];
+        if (k > 8 || !need(k)) return false;
+        uint64_t u = 0;
+        for (unsigned b = 0; b < k; ++b) u |= (uint64_t)p[i + b] << (8 * b);
+        if (k && k < 8 && (p[i + k - 1] & 0x80)) u |= ~(uint64_t)0 << (8 * k);
+        i += k;
+        v.kind = PVal::INT;
+        v.i = (int64_t)u;
+        st.push_back(std::move(v));
+        break;
+      }
+      case 'X': {  // BINUNICODE
+        if (!need(4)) return false;
+        const size_t k = rd32(p + i);
+        i += 4;
+        if (!need(k)) return false;
+        v.kind = PVal::STR;
+        v.s.assign((const char*)p + i, k);
+        i += k;
+        st.push_back(std::move(v));
+        break;
+      }
+      case 0x8c: {  // SHORT_BINUNICODE (protocol 4 writers)
+        if (!need(1)) return false;
+        const size_t k = p[i++];
+        if (!need(k)) return false;
+        v.kind = PVal::STR;
+        v.s.assign((const char*)p + i, k);
+        i += k;
+        st.push_back(std::move(v));
+        break;
+      }
+      case 'c': {  // GLOBAL "module\nname\n"
+        const uint8_t* a = (const uint8_t*)memchr(p + i, '\n', n - i);
+        if (!a) return false;
+        const uint8_t* b = (const uint8_t*)memchr(a + 1, '\n', n - (size_t)(a + 1 - p));
+        if (!b) return false;
+        v.kind = PVal::GLOBAL;
+        v.s.assign((const char*)p + i, (size_t)(a - (p + i)));
+        v.s += ' ';
+        v.s.append((const char*)a + 1, (size_t)(b - a - 1));
+        i = (size_t)(b + 1 - p);
+        st.push_back(std::move(v));
+        break;
+      }
+      case 'q':
+        if (!need(1) || !set_memo(p[i])) return false;
+        i += 1;
+        break;
+      case 'r':
+        if (!need(4) || !set_memo(rd32(p + i))) return false;
+        i += 4;
+        break;
+      case 0x94:  // MEMOIZE
+        if (!set_memo(memo.size())) return false;
+        break;
+      case 'h':
+      case 'j': {
+        const size_t w = op == 'h' ? 1 : 4;
+        if (!need(w)) return false;
+        const size_t k = op == 'h' ? p[i] : rd32(p + i);
+        i += w;
+        if (k >= memo.size()) return false;
+        st.push_back(memo[k]);
+        break;
+      }
+      case 't':
+        v.kind = PVal::TUPLE;
+        if (!pop_to_mark(v.items)) return false;
+        st.push_back(std::move(v));
+        break;
+      case 0x85:
+        if (!tuple_of(1)) return false;
+        break;
+      case 0x86:
+        if (!tuple_of(2)) return false;
+        break;
+      case 0x87:
+        if (!tuple_of(3)) return false;
+        break;
+      case 'Q': {  // BINPERSID: ("storage", <torch XStorage>, key, location, numel)
+        if (st.empty()) return false;
+        PVal pid = std::move(st.back());
+        st.pop_back();
+        if (pid.kind != PVal::TUPLE || pid.items.size() != 5 || pid.items[0].kind != PVal::STR || pid.items[0].s != "storage" ||
+            pid.items[1].kind != PVal::GLOBAL || pid.items[2].kind != PVal::STR || pid.items[4].kind != PVal::INT)
+          return false;
+        v.kind = PVal::STORAGE;
+        for (int k = 0; k < (int)(sizeof(kStorage) / sizeof(kStorage[0])); ++k)
+          if (pid.items[1].s == std::string("torch ") + kStorage[k].name) v.t.dtype = k;
+        if (v.t.dtype < 0) return false;
+        v.t.key = pid.items[2].s;
+        v.t.storage_numel = pid.items[4].i;
+        st.push_back(std::move(v));
+        break;
+      }
+      case 'R': {  // REDUCE: callable(*args)
+        if (st.size() < 2) return false;
+        PVal args = std::move(st.back());
+        st.pop_back();
+        PVal fn = std::move(st.back());
+        st.pop_back();
+        if (fn.kind != PVal::GLOBAL || args.kind != PVal::TUPLE) return false;
+        if (fn.s == "collections OrderedDict" && args.items.empty()) {
+          v.kind = PVal::OPAQUE;  // backward hooks
+        } else if (fn.s == "torch._utils _rebuild_tensor_v2" && args.items.size() >= 5 && args.items[0].kind == PVal::STORAGE &&
+                   args.items[1].kind == PVal::INT) {
+          v.kind = PVal::TENSOR;
+          v.t = args.items[0].t;
+          v.t.offset = args.items[1].i;
+          if (!ints(args.items[2], v.t.shape) || !ints(args.items[3], v.t.stride) || v.t.shape.size() != v.t.stride.size()) return false;
+        } else {
+          return false;
+        }
+        st.push_back(std::move(v));
+        break;
+      }
+      case 's': {  // SETITEM
+        if (st.size() < 3 || st[st.size() - 3].kind != PVal::DICT) return false;
+        PVal val = std::move(st.back());
+        st.pop_back();
+        PVal key = std::move(st.back());
+        st.pop_back();
+        st.back().items.push_back(std::move(key));
+        st.back().items.push_back(std::move(val));
+        break;
+      }
+      case 'u': {  // SETITEMS
+        std::vector<PVal> kv;
+        if (!pop_to_mark(kv) || kv.size() % 2 || st.empty() || st.back().kind != PVal::DICT) return false;
+        for (PVal& x : kv) st.back().items.push_back(std::move(x));
+        break;
+      }
+      case '.': {
+        if (st.size() != 1 || st[0].kind != PVal::DICT) return false;
+        const std::vector<PVal>& kv = st[0].items;
+        for (size_t k = 0; k + 1 < kv.size(); k += 2) {
+          if (kv[k].kind != PVal::STR || kv[k + 1].kind != PVal::TENSOR) return false;
+          out.emplace_back(kv[k].s, kv[k + 1].t);
+        }
+        return true;
+      }
+      default:
+        return false;
+    }
+  }
+  return false;  // no STOP
+}
+
+// One tensor of the file, resolved against its storage entry: element (r, c[, k]) by shape / stride / offset.
+struct PtView {
+  const uint8_t* base = nullptr;
+  int dtype = -1;
+  int64_t offset = 0;
+  int64_t shape[3] = {1, 1, 1}, stride[3] = {0, 0, 0};
+  int dims = 0;
+  bool contiguous = false;
+  int64_t at_i64(int64_t r, int64_t c) const {
+    const int64_t e = offset + r * stride[0] + c * stride[1];
+    switch (dtype) {
+      case ST_LONG: return ((const int64_t*)base)[e];
+      case ST_CHAR: return ((const int8_t*)base)[e];
+      case ST_INT: return ((const int32_t*)base)[e];
+      case ST_SHORT: return ((const int16_t*)base)[e];
+      default: return base[e];  // ByteStorage, BoolStorage
+    }
+  }
+};
+
 bool load_one(const char* path, int64_t ignore_label, PtRows& out) {
   const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
   if (fd < 0) return false;
@@ -713,8 +1015,17 @@ bool load_one(const char* path, int64_t ignore_label, PtRows& out) {
     const unsigned n_entries = rd16(f + e + 10);
     const size_t cd_size = rd32(f + e + 12), cd_off = rd32(f + e + 16);
     if (cd_off + cd_size > size) break;
-    const uint8_t* sec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t len[5] = {0, 0, 0, 0, 0};
+    // every STORED entry "<stem>/data.pkl" and "<stem>/data/<key>": where its bytes lie, and the directory's CRC of them
+    struct Ent {
+      std::string key;
+      const uint8_t* p;
+      size_t n;
+      uint32_t crc;
+    };
+    std::vector<Ent> ents;
+    const uint8_t* pkl = nullptr;
+    size_t pkl_len = 0;
+    uint32_t pkl_crc = 0;
     size_t p = cd_off;
     bool bad = false;
     for (unsigned i = 0; i < n_entries; ++i) {
@@ -724,16 +1035,18 @@ bool load_one(const char* path, int64_t ignore_label, PtRows& out) {
       }
       const unsigned method = rd16(f + p + 10), nlen = rd16(f + p + 28), xlen = rd16(f + p + 30), clen = rd16(f + p + 32);
       const size_t csize = rd32(f + p + 20), usize = rd32(f + p + 24), lho = rd32(f + p + 42);
-      const char* name = (const char*)f + p + 46;
+      const uint32_t crc = rd32(f + p + 16);
       if (p + 46 + nlen > size) {
         bad = true;
         break;
       }
-      // "<anything>/data/<k>", k = 0 .. 4
-      if (nlen >= 7 && name[nlen - 2] == '/' && memcmp(name + nlen - 7, "/data/", 6) == 0 && name[nlen - 1] >= '0' && name[nlen - 1] <= '4') {
-        const int k = name[nlen - 1] - '0';
+      const std::string name((const char*)f + p + 46, nlen);
+      const size_t dpos = name.rfind("/data/");
+      const bool is_pkl = nlen >= 9 && name.compare(nlen - 9, 9, "/data.pkl") == 0;
+      const bool is_storage = dpos != std::string::npos && name.find('/', dpos + 6) == std::string::npos && dpos + 6 < nlen;
+      if (is_pkl || is_storage) {
         if (method != 0 || csize != usize || csize == 0xffffffffu || lho + 30 > size || rd32(f + lho) != 0x04034b50u) {
-          bad = true;
+          bad = true;  // deflated or ZIP64: not what torch.save or this library's writer emits
           break;
         }
         const size_t data = lho + 30 + rd16(f + lho + 26) + rd16(f + lho + 28);
@@ -741,33 +1054,90 @@ bool load_one(const char* path, int64_t ignore_label, PtRows& out) {
           bad = true;
           break;
         }
-        sec[k] = f + data;
-        len[k] = usize;
+        if (is_pkl) {
+          pkl = f + data;
+          pkl_len = usize;
+          pkl_crc = crc;
+        } else {
+          ents.push_back({name.substr(dpos + 6), f + data, usize, crc});
+        }
       }
       p += 46 + nlen + xlen + clen;
     }
-    if (bad || !sec[0] || !sec[1] || !sec[4] || len[4] == 0 || len[4] % 2048) break;
-    const size_t B = len[4] / 2048;
-    if (len[1] % (8 * B)) break;
-    const size_t L = len[1] / (8 * B);
-    if (L == 0 || len[0] != B * L * 8 || ((uintptr_t)sec[0] & 3) || ((uintptr_t)sec[1] & 7) || ((uintptr_t)sec[4] & 7)) break;
-    const float* logit = (const float*)sec[0];
-    const int64_t* target = (const int64_t*)sec[1];
-    const int64_t* idm = (const int64_t*)sec[4];
-    for (size_t r = 0; r < B; ++r) {
-      const int64_t* row = idm + r * 256;
-      const int64_t n = row[0];
-      if (n < 0 || n > 254) {
+    if (bad || !pkl || crc32_fast(pkl, pkl_len) != pkl_crc) break;
+    std::vector<std::pair<std::string, PtTensor>> tensors;
+    if (!parse_pickle(pkl, pkl_len, tensors)) break;
+    // the three tensors the chop driver needs (src/smooth/predict.rs:266-300): prediction [B, L, 2] floating point,
+    // target [B, L] and id [B, 256] of any integer storage (CustomWriter widens them to int64; files of older writers hold
+    // the collator's int8, deepchopper/models/llm/tokenizer.py:89-91)
+    PtView view[3];
+    const char* want[3] = {"prediction", "target", "id"};
+    for (int w = 0; w < 3 && !bad; ++w) {
+      const PtTensor* t = nullptr;
+      for (const auto& kv : tensors)
+        if (kv.first == want[w]) t = &kv.second;
+      const Ent* en = nullptr;
+      if (t)
+        for (const Ent& x : ents)
+          if (x.key == t->key) en = &x;
+      const int dims = w == 0 ? 3 : 2;
+      if (!t || !en || (int)t->shape.size() != dims || t->offset < 0 || t->storage_numel < 0 ||
+          (w == 0 ? t->dtype != ST_FLOAT : (t->dtype == ST_FLOAT || t->dtype == ST_DOUBLE))) {
         bad = true;
         break;
       }
-      for (int64_t c = 0; c < n; ++c) out.names.push_back((char)row[2 + c]);
+      const int width = kStorage[t->dtype].width;
+      if ((size_t)t->storage_numel * (size_t)width != en->n || ((uintptr_t)en->p & (uintptr_t)(width - 1))) {
+        bad = true;
+        break;
+      }
+      PtView& v = view[w];
+      v.base = en->p;
+      v.dtype = t->dtype;
+      v.offset = t->offset;
+      v.dims = dims;
+      int64_t last = t->offset, dense = 1;
+      v.contiguous = true;
+      for (int d = dims - 1; d >= 0; --d) {
+        v.shape[d] = t->shape[(size_t)d];
+        v.stride[d] = t->stride[(size_t)d];
+        if (v.shape[d] < 0 || v.stride[d] < 0) bad = true;
+        if (v.shape[d] > 1 && v.stride[d] != dense) v.contiguous = false;
+        dense *= v.shape[d];
+        if (v.shape[d] > 0) last += (v.shape[d] - 1) * v.stride[d];
+      }
+      if (bad || (dense > 0 && last >= t->storage_numel)) {  // an element outside its storage
+        bad = true;
+        break;
+      }
+      if (crc32_fast(en->p, en->n) != en->crc) bad = true;  // (torch.load's miniz checks it too; candle's zip crate as well)
+    }
+    if (bad) break;
+    const int64_t B = view[0].shape[0], L = view[0].shape[1];
+    if (view[0].shape[2] != 2 || view[1].shape[0] != B || view[1].shape[1] != L || view[2].shape[0] != B || view[2].shape[1] < 2) break;
+    const int64_t id_cols = view[2].shape[1];
+    const float* logit = (const float*)view[0].base;
+    for (int64_t r = 0; r < B; ++r) {
+      const int64_t n = view[2].at_i64(r, 0);
+      if (n < 0 || n + 2 > id_cols) {
+        bad = true;
+        break;
+      }
+      for (int64_t c = 0; c < n; ++c) out.names.push_back((char)view[2].at_i64(r, 2 + c));
       out.name_off.push_back((int64_t)out.names.size());
-      out.truncated.push_back(row[1] != 0);
-      const float* lg = logit + r * L * 2;
-      const int64_t* tg = target + r * L;
-      for (size_t c = 0; c < L; ++c)
-        if (tg[c] != ignore_label) out.labels.push_back(lg[2 * c + 1] > lg[2 * c] ? 1 : 0);  // argmax, first maximum wins
+      out.truncated.push_back(view[2].at_i64(r, 1) != 0);
+      if (view[0].contiguous && view[1].contiguous && view[1].dtype == ST_LONG) {  // what CustomWriter and dc_pt_submit write
+        const float* lg = logit + view[0].offset + r * L * 2;
+        const int64_t* tg = (const int64_t*)view[1].base + view[1].offset + r * L;
+        for (int64_t c = 0; c < L; ++c)
+          if (tg[c] != ignore_label) out.labels.push_back(lg[2 * c + 1] > lg[2 * c] ? 1 : 0);  // argmax, first maximum wins
+      } else {
+        for (int64_t c = 0; c < L; ++c) {
+          if (view[1].at_i64(r, c) == ignore_label) continue;
+          const int64_t e0 = view[0].offset + r * view[0].stride[0] + c * view[0].stride[1];
+          out.labels.push_back(logit[e0 + view[0].stride[2]] > logit[e0] ? 1 : 0);
+        }
+      }
       out.label_off.push_back((int64_t)out.labels.size());
     }
     ok = !bad;

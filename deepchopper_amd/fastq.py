@@ -117,7 +117,7 @@ class FastqReader:
     [b0, b1) -- ranks tile the file with `shard_byte_range` and never parse each other's reads."""
 
     def __init__(self, path: str, *, byte_range: tuple[int, int] | None = None, readahead: int = 4,
-                 full_header: bool = False):
+                 full_header: bool = False, strict_four_line: bool = False):
         self.path = str(path)
         self.full_header = bool(full_header)  # chunks carry whole definition lines (the chop stage needs them)
         self._h = C.c_void_p()
@@ -129,6 +129,8 @@ class FastqReader:
         if rc:
             self._h = C.c_void_p()
             _iolib.raise_for(rc)
+        if strict_four_line:  # `chop` reads as noodles does; `predict` (the default) as kseq does
+            _iolib.raise_for(L.dc_fq_set_strict(self._h, 1))
         self._cap = (0, 0, 0)
         self._bufs = None
 

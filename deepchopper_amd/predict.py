@@ -587,17 +587,17 @@ class PtWriter:
         """Launches whose payload has arrived in host memory go to the writer threads (in order)."""
         import ctypes as C
 
-        first = True
-        while self._staged and ((block and first) or self._staged[0][0].query()):
-            first = False
+        oldest = True  # (block=True waits for ONE launch, the oldest; the rest go only if their copy has landed)
+        while self._staged and ((block and oldest) or self._staged[0][0].query()):
+            oldest = False
             copied, args, _dev_keep, pinned = self._staged.pop(0)
             t0 = time.perf_counter()
             copied.synchronize()
             self.timers["wait_copy"] += time.perf_counter() - t0
-            d, rank, first, row0, subs, n_cols, pay_off, total, n, names, offs, truncated = args
+            d, rank, first_index, row0, subs, n_cols, pay_off, total, n, names, offs, truncated = args
             ticket = C.c_int64(0)
             ptr = lambda a: C.c_void_p(a.ctypes.data)
-            rc = self._io.lib().dc_pt_submit_packed(self._h, d, rank, first, len(subs), ptr(row0), ptr(subs), ptr(n_cols), ptr(pay_off),
+            rc = self._io.lib().dc_pt_submit_packed(self._h, d, rank, first_index, len(subs), ptr(row0), ptr(subs), ptr(n_cols), ptr(pay_off),
                                                     C.c_void_p(pinned.data_ptr()), total, n, C.c_char_p(names), ptr(offs),
                                                     ptr(truncated), C.byref(ticket))
             if rc:

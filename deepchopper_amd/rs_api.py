@@ -501,7 +501,7 @@ def load_predicts_from_batch_pt(pt_path, ignore_label: int = IGNORE_LABEL) -> di
 
 def load_predicts_from_batch_pts(pt_path, ignore_label: int = IGNORE_LABEL, max_predicts: int | None = None):
     """src/smooth/predict.rs:211-261."""
-    files = []
+    files = [os.fspath(pt_path)] if os.path.isfile(pt_path) and os.fspath(pt_path).endswith(".pt") else []
     for root, _, names in os.walk(os.fspath(pt_path)):
         files += [os.path.join(root, n) for n in names if n.endswith(".pt")]
     if max_predicts is not None:
@@ -523,9 +523,10 @@ class LabelStore:
     the reference's "load pt ... fail" line if that fails too.  `index`: id -> row, a later file winning as in the
     reference's HashMap."""
 
-    def __init__(self, labels: np.ndarray, offsets: np.ndarray, ids: list[str], truncated: np.ndarray):
+    def __init__(self, labels: np.ndarray, offsets: np.ndarray, ids: list[str], truncated: np.ndarray, fallback_files=()):
         self.labels, self.offsets, self.ids, self.truncated = labels, offsets, ids, truncated
         self.index = {rid: i for i, rid in enumerate(ids)}
+        self.fallback_files = list(fallback_files)  # files the native reader did not recognise (read through torch.load, or skipped)
 
     def __len__(self) -> int:
         return len(self.index)
@@ -545,7 +546,7 @@ class LabelStore:
 
         files = []
         for d in ([pt_paths] if isinstance(pt_paths, (str, os.PathLike)) else pt_paths):
-            found = []
+            found = [os.fspath(d)] if os.path.isfile(d) and os.fspath(d).endswith(".pt") else []  # (WalkDir yields a file root itself)
             for root, _, names in os.walk(os.fspath(d)):
                 found += [os.path.join(root, n) for n in names if n.endswith(".pt")]
             files += found[:max_predicts] if max_predicts is not None else found
@@ -568,9 +569,10 @@ class LabelStore:
         text = names[: nb.value].tobytes().decode("latin1")
         ids = [text[noffs[i]: noffs[i + 1]] for i in range(n.value)]
         trunc = trunc[: n.value].astype(bool)
-        if nf.value:  # the general path for what the native reader left alone
+        fallback = [files[i] for i in np.flatnonzero(failed[: len(files)])] if nf.value else []
+        if fallback:  # the general path for what the native reader left alone
             extra_l, extra_ids, extra_t = [labels], list(ids), [trunc]
-            for f in (files[i] for i in np.flatnonzero(failed[: len(files)])):
+            for f in fallback:
                 try:
                     for rid, p in load_predicts_from_batch_pt(f, ignore_label).items():
                         extra_l.append(np.asarray(p.prediction, np.int8))
@@ -582,4 +584,4 @@ class LabelStore:
             labels = np.concatenate(extra_l) if len(extra_l) > 1 else labels
             offs = np.concatenate([offs, offs[-1] + np.cumsum(sizes[1:], dtype=np.int64)]) if len(sizes) > 1 else offs
             ids, trunc = extra_ids, np.concatenate(extra_t)
-        return LabelStore(labels, offs, ids, trunc)
+        return LabelStore(labels, offs, ids, trunc, fallback)

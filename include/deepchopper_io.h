@@ -95,6 +95,13 @@ int dc_fq_read_chunk_full(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint
 
 /* records delivered so far / compressed-or-plain bytes consumed so far */
 int64_t dc_fq_records_read(const dc_fq_reader* r);
+
+/* Record grammar.  Default (0): what kseq accepts -- `predict` reads with pyfastx.Fastx (deepchopper/data/only_fq.py:34):
+ * sequence and quality may wrap over several lines.  strict_four_line = 1: exactly four lines per record, what noodles'
+ * fastq reader accepts -- the reference's `chop` reads with it (src/output/writefq.rs:172-199, src/bin/predict.rs:275-316):
+ * a record whose quality line is shorter than its sequence is the reference's "Sequence/quality length mismatch" error,
+ * never the start of a wrapped quality that swallows the next record.  Set before the first read. */
+int dc_fq_set_strict(dc_fq_reader* r, int strict_four_line);
 int64_t dc_fq_bytes_consumed(const dc_fq_reader* r);
 void dc_fq_close(dc_fq_reader* r);
 

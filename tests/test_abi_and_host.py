@@ -8,6 +8,8 @@ import pytest
 
 from deepchopper_amd import _lib
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_library_exports_every_header_symbol(hip_lib):
     syms = _lib.header_symbols()
@@ -403,3 +405,105 @@ def test_native_pt_loader_survives_damaged_files(tmp_path):
     assert len(store.ids) <= 6 * cases
     assert store.labels.size == 0 or (set(np.unique(store.labels).tolist()) <= {0, 1})
     assert all(len(i) <= 254 for i in store.ids)
+
+
+def test_pt_writer_flush_block_waits_for_one_launch_only():
+    """PtWriter._flush(block=True) (what `_bound` calls when too much is in flight) synchronises on the OLDEST staged launch and
+    hands on only those whose copy has already landed; round 5's loop reused one name for its flag and for the launch's first
+    file index, so with a non-zero index it blocked on every staged launch.  `_bound()` brings the total back to `max_inflight`
+    with one wait."""
+    import numpy as np
+
+    from deepchopper_amd.predict import PtWriter
+
+    class Event:
+        def __init__(self):
+            self.done, self.waited = False, 0
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.waited += 1
+            self.done = True
+
+    class Pinned:
+        def data_ptr(self):
+            return 0
+
+    class Lib:
+        def __init__(self):
+            self.calls = []
+
+        def dc_pt_submit_packed(self, h, d, rank, first_index, n_files, *rest):
+            self.calls.append((rank, first_index, n_files))
+            return 0
+
+        def dc_pt_wait(self, h, ticket):
+            return 0
+
+        def dc_pt_close(self, h):
+            return 0
+
+    class Io:
+        def __init__(self):
+            self._lib = Lib()
+
+        def lib(self):
+            return self._lib
+
+        def raise_for(self, rc):
+            assert rc == 0
+
+    w = PtWriter(threads=1, max_inflight=3)
+    real_io, real_h = w._io, w._h
+    w._io = Io()
+    try:
+        i32, i64 = np.zeros(1, np.int32), np.zeros(1, np.int64)
+        events = [Event() for _ in range(5)]
+        for k, ev in enumerate(events):  # first file index 7, 8, ... : never zero
+            args = (b"/nowhere", 0, 7 + k, i32, i32, i32, i64, 0, 0, b"", i64, np.zeros(1, np.uint8))
+            w._staged.append((ev, args, None, Pinned()))
+        w._flush(block=True)
+        assert [e.waited for e in events] == [1, 0, 0, 0, 0] and len(w._staged) == 4
+        assert w._io.lib().calls == [(0, 7, 1)]
+        events[2].done = True  # its copy has landed: goes along with the oldest, and the loop stops at the fourth
+        w._flush(block=True)
+        assert [e.waited for e in events] == [1, 1, 1, 0, 0] and len(w._staged) == 2
+        assert w._io.lib().calls == [(0, 7, 1), (0, 8, 1), (0, 9, 1)]
+        w._pending.clear()
+        w._staged.extend((ev, (b"/nowhere", 0, 20 + k, i32, i32, i32, i64, 0, 0, b"", i64, np.zeros(1, np.uint8)), None, Pinned())
+                         for k, ev in enumerate([Event(), Event()]))
+        n_calls = len(w._io.lib().calls)
+        w._bound()  # 4 staged, nothing pending, max_inflight 3 -> exactly one launch handed on (and its files waited for)
+        assert len(w._staged) == 3 and len(w._pending) == 0 and len(w._io.lib().calls) == n_calls + 1
+        assert [e.waited for e in events[3:]] == [1, 0]
+    finally:
+        w._staged.clear()
+        w._pending.clear()
+        w._io, w._h = real_io, real_h
+        w.close()
+
+
+def test_makefile_knows_every_header_the_host_library_includes():
+    """`make` must rebuild libdeepchopper_io.so when any header it includes changes (round 5: fast_deflate.h was not a
+    prerequisite, so editing the DEFLATE encoder alone left a stale library that build(force=False) would ship)."""
+    import re
+    import subprocess
+
+    csrc = os.path.join(ROOT, "deepchopper_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j4"], check=True, capture_output=True)
+    assert subprocess.run(["make", "-C", csrc, "-q"], capture_output=True).returncode == 0
+    included = set()
+    for src in ("fastq_io.cpp", "pt_io.cpp"):
+        included |= {os.path.basename(h) for h in re.findall(r'#include "([^"]+)"', open(os.path.join(csrc, src)).read())}
+    assert {"fast_deflate.h", "fast_inflate.h", "deepchopper_io.h"} <= included
+    for h in sorted(included):
+        path = os.path.join(csrc, h) if os.path.exists(os.path.join(csrc, h)) else os.path.join(ROOT, "include", h)
+        st = os.stat(path)
+        try:
+            os.utime(path, None)
+            assert subprocess.run(["make", "-C", csrc, "-q", "../lib/libdeepchopper_io.so"], capture_output=True).returncode == 1, h
+        finally:
+            os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert subprocess.run(["make", "-C", csrc, "-q"], capture_output=True).returncode == 0

@@ -383,3 +383,41 @@ def test_multi_line_fastq_is_read_like_kseq_reads_it(tmp_path):
     with pytest.raises(Exception, match="cannot be split by byte ranges"):
         with FastqReader(str(plain), byte_range=(0, len(text) // 2)) as rd:
             list(rd.chunks(1000, 1 << 30))
+
+
+def test_strict_four_line_reader_is_what_chop_uses(tmp_path):
+    """`chop` reads as noodles does (src/output/writefq.rs:172-199): exactly four lines per record.  A record whose
+    quality line is shorter than its sequence raises the reference's length-mismatch error there even when the following
+    lines would add up to a wrapped quality; the `predict` reader (kseq's grammar) accepts that very file as ONE record."""
+    import inspect
+
+    from deepchopper_amd import chop
+    from deepchopper_amd.fastq import FastqReader
+
+    # record r1: 12 bases, quality line of 4; the next "record" (@IIII / IIII / + / ...) has exactly the 8 missing characters
+    # on its first two lines, so the kseq grammar swallows them as quality.
+    text = "@r1\nACGTACGTACGT\n+\nIIII\n@III\nIIII\n@r3\nACGT\n+\nIIII\n"
+    p = tmp_path / "short_qual.fq"
+    p.write_text(text)
+    with FastqReader(str(p)) as rd:  # predict's reader
+        ch = rd.read_chunk()
+        assert ch.n == 2 and ch.names() == ["r1", "r3"]
+        assert bytes(ch.qual[: ch.offsets[1]]) == b"IIII@IIIIIII"
+    with FastqReader(str(p), strict_four_line=True) as rd:
+        with pytest.raises(Exception, match="Sequence/quality length mismatch in record 'r1': seq=12, qual=4"):
+            rd.read_chunk()
+    # a wrapped sequence is a format error for the strict reader, a record for the default one
+    q = tmp_path / "wrapped.fq"
+    q.write_text("@w\nACGT\nACGT\n+\nIIIIIIII\n")
+    with FastqReader(str(q)) as rd:
+        assert rd.read_chunk().n == 1
+    with FastqReader(str(q), strict_four_line=True) as rd:
+        with pytest.raises(Exception, match="no '\\+' separator"):
+            rd.read_chunk()
+    # ordinary four-line files read the same either way
+    r = tmp_path / "plain.fq"
+    r.write_text("@a x\nACGT\n+\n!!!!\n@b\nGG\n+a\nII\n")
+    with FastqReader(str(r), strict_four_line=True) as rd:
+        ch = rd.read_chunk()
+        assert ch.n == 2 and ch.names() == ["a", "b"]
+    assert inspect.getsource(chop).count("strict_four_line=True") == 2  # both chop drivers

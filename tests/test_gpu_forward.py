@@ -981,3 +981,108 @@ def test_shared_prefix_forms_error_vs_float64(hip_lib):
         assert errs[f"{mode}/linear"] <= 1.5 * max(errs[f"{mode}/padded"], errs["oracle_f32"]) + 2e-5, errs
         assert errs[f"{mode}/exact"] <= 1.5 * max(errs[f"{mode}/padded"], errs["oracle_f32"]) + 2e-5, errs
         assert errs[f"{mode}/linear"] < ATOL and errs[f"{mode}/padded"] < ATOL
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the linear prefix form where it is worst, and over many seeds
+# ----------------------------------------------------------------------------------------------------------------
+_F64_CACHE: dict = {}
+
+
+def _form_errors(model, ops, ids, q, first, ntok, npad):
+    """max |dlogit| over the rows' positions of both shared-prefix forms against the padded launch; returns the three logit
+    arrays as well."""
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    padded = model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()
+    out = {}
+    try:
+        for form in ("exact", "linear"):
+            model.set_prefix_mode(form)
+            out[form] = model.forward_shared_prefix(d_ids, d_q, first, ntok, npad).cpu().numpy()
+    finally:
+        model.set_prefix_mode("exact")
+    mask = np.zeros(ids.shape, bool)
+    for r in range(len(ntok)):
+        mask[r, first[r]: first[r] + ntok[r]] = True
+    return padded, out, mask
+
+
+def test_linear_prefix_form_at_the_longest_pad_run(env):
+    """A ~100-token read behind a ~32 600-token pad run (the batch's longest read fills the model's whole context: the shared
+    row takes the four-step 2^15 transform), the case in which `k * (z - z_pad) + F` leans hardest on F: both forms against
+    the padded launch AND against a float64 evaluation of the oracle on the padded batch.  The linear form must be no
+    further from the float64 truth than the padded launch is (its own reads run on shorter, exactly causal kernels)."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(32769)
+    batches = [[32769, 100, 4000], [32768 - 3, 150]]
+    ids, q, first, ntok, npad = _padded_launch(rng, batches)
+    assert int(npad.max()) >= 32600
+    padded, forms, mask = _form_errors(model, ops, ids, q, first, ntok, npad)
+    assert model.prefix_violations() == 0
+    ref64 = _F64_CACHE.get("longest_pad_run")  # (the same weights and inputs in every GEMM mode: evaluated once)
+    if ref64 is None:
+        ref64 = np.zeros_like(padded, dtype=np.float64)
+        r = 0
+        for b in batches:
+            c0 = ids.shape[1] - max(b)
+            ref64[r: r + len(b), c0:] = fr.forward(sd, ids[r: r + len(b), c0:].astype(np.int64), q[r: r + len(b), c0:], dtype=torch.float64).numpy()
+            r += len(b)
+        _F64_CACHE["longest_pad_run"] = ref64
+    e = {"padded": float(np.abs(padded - ref64)[mask].max())}
+    for form in ("exact", "linear"):
+        e[f"{form}_vs_padded"] = float(np.abs(forms[form] - padded)[mask].max())
+        e[form] = float(np.abs(forms[form] - ref64)[mask].max())
+    # the short reads' own tokens (what the chop stage consumes) on their own
+    own = np.zeros_like(mask)
+    for r in range(len(ntok)):
+        own[r, first[r] + npad[r]: first[r] + ntok[r]] = True
+    e["linear_own_tokens"] = float(np.abs(forms["linear"] - ref64)[own].max())
+    e["padded_own_tokens"] = float(np.abs(padded - ref64)[own].max())
+    print(f"longest pad run ({model.gemm_mode}): max |dlogit| {({k: f'{v:.2e}' for k, v in e.items()})}")
+    assert e["linear_vs_padded"] <= ATOL and e["exact_vs_padded"] <= ATOL, e
+    assert e["linear"] <= ATOL and e["exact"] <= ATOL and e["padded"] <= ATOL, e
+    assert e["linear"] <= 1.5 * e["padded"] + 2e-5, e
+    lab = lambda x: x[..., 1] > x[..., 0]
+    sure = (np.abs(ref64[..., 1] - ref64[..., 0]) > 2 * ATOL) & mask
+    assert np.array_equal(lab(forms["linear"])[sure], lab(ref64)[sure])
+
+
+def test_linear_prefix_form_over_twenty_seeds(env):
+    """The driver's reference_b12_nanopore check saw 1.64e-4 against the torch-fp32 oracle on one seed (82 % of the suite's
+    2e-4).  Twenty seeds of the same nanopore-like length mix in the reference's batches of 12: max |dlogit| of the linear
+    form against the padded launch (every seed) and against the float64 oracle (five seeds, one batch each), printed as a
+    distribution; argmax labels of the linear form, the exact form and the padded launch agree wherever the margin exceeds the
+    observed difference."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    vs_padded, vs_f64, padded_vs_f64, flips = [], [], [], 0
+    for seed in range(20):
+        rng = np.random.default_rng(1000 + seed)
+        batches = [list(_nanopore_lens(rng, 12, 12000)) for _ in range(3)]
+        ids, q, first, ntok, npad = _padded_launch(rng, batches)
+        padded, forms, mask = _form_errors(model, ops, ids, q, first, ntok, npad)
+        d = np.abs(forms["linear"] - padded)
+        vs_padded.append(float(d[mask].max()))
+        margin = np.abs(padded[..., 1] - padded[..., 0])
+        lab = lambda x: x[..., 1] > x[..., 0]
+        diff = lab(forms["linear"]) != lab(padded)
+        assert not (diff & mask & (margin > 2 * d.max(axis=-1))).any()
+        flips += int((diff & mask).sum())
+        if seed % 4 == 0:  # float64 truth for the first batch (12 rows, its own padded width)
+            b = batches[0]
+            c0 = ids.shape[1] - max(b)
+            ref64 = _F64_CACHE.get(("seeds", seed))
+            if ref64 is None:
+                ref64 = _F64_CACHE[("seeds", seed)] = fr.forward(sd, ids[: len(b), c0:].astype(np.int64), q[: len(b), c0:], dtype=torch.float64).numpy()
+            vs_f64.append(float(np.abs(forms["linear"][: len(b), c0:] - ref64).max()))
+            padded_vs_f64.append(float(np.abs(padded[: len(b), c0:] - ref64).max()))
+    assert model.prefix_violations() == 0
+    v = np.array(vs_padded)
+    print(f"linear form vs padded launch over 20 seeds ({model.gemm_mode}): median {np.median(v):.2e}, p90 {np.quantile(v, 0.9):.2e}, "
+          f"max {v.max():.2e}; vs float64 oracle (5 seeds): linear max {max(vs_f64):.2e}, padded launch max {max(padded_vs_f64):.2e}; "
+          f"labels differing inside the noise margin: {flips}")
+    assert v.max() <= ATOL, v
+    assert max(vs_f64) <= ATOL and max(vs_f64) <= 1.5 * max(padded_vs_f64) + 2e-5, (vs_f64, padded_vs_f64)

@@ -1,0 +1,113 @@
+"""The native `.pt` reader (libdeepchopper_io: dc_pt_load) on the REFERENCE's own prediction files.
+
+`tests/golden/pt/chunk{0,1}/{0,1,2}.pt` are the reference's committed `CustomWriter` outputs (its `tests/data/eval/`; data, kept
+byte for byte).  The reference pins its loader on chunk0/0.pt: `test_load_predict`, src/smooth/predict.rs:323-330, `len == 12`.
+chunk1 was written by an older writer that stored `target` and `id` as the collator's int8 (`torch CharStorage`,
+deepchopper/models/llm/tokenizer.py:89-91) instead of CustomWriter's int64 (deepchopper/models/callbacks.py:21-22); candle's
+pickle reader knows no CharStorage, so the reference's own chop could not read those three -- this reader parses `data.pkl`
+(dtype, shape, stride, storage offset per key) and reads both layouts.
+"""
+import os
+import shutil
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from deepchopper_amd import rs_api
+
+PT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pt")
+FILES = [(c, i) for c in (0, 1) for i in (0, 1, 2)]
+
+
+def _expect(path):
+    """torch.load -> first-max argmax over the unmasked positions, ids, truncation flags (src/smooth/predict.rs:264-317)."""
+    d = torch.load(path, map_location="cpu", weights_only=True)
+    lg, tg, idm = d["prediction"].numpy(), d["target"].numpy().astype(np.int64), d["id"].numpy().astype(np.int64)
+    out = {}
+    for r in range(lg.shape[0]):
+        n = int(idm[r, 0])
+        rid = "".join(chr(c) for c in idm[r, 2: 2 + n])
+        out[rid] = ((lg[r, :, 1] > lg[r, :, 0]).astype(np.int8)[tg[r] != -100], bool(idm[r, 1] != 0))
+    return d, out
+
+
+@pytest.mark.parametrize("chunk,i", FILES)
+def test_native_reader_on_the_reference_files(chunk, i):
+    path = os.path.join(PT, f"chunk{chunk}", f"{i}.pt")
+    d, want = _expect(path)
+    assert d["target"].dtype == (torch.int64 if chunk == 0 else torch.int8)  # the two writer generations
+    store = rs_api.LabelStore.load([path], threads=1)
+    assert store.fallback_files == [], "the native reader must recognise the reference's own files"
+    assert len(store) == 12 == len(want)  # src/smooth/predict.rs:328
+    for rid, (lab, trunc) in want.items():
+        k = store.index[rid]
+        assert np.array_equal(store.labels[store.offsets[k]: store.offsets[k + 1]], lab), rid
+        assert bool(store.truncated[k]) == trunc
+
+
+def test_native_reader_on_the_reference_directories():
+    """load_predicts_from_batch_pts over the two directories as `deepchopper chop <dir>` walks them: 36 reads each, all native."""
+    for chunk in (0, 1):
+        store = rs_api.LabelStore.load(os.path.join(PT, f"chunk{chunk}"), threads=3)
+        assert len(store) == 36 and store.fallback_files == []
+
+
+def _rewrite(src, dst, edit):
+    """Copy a `.pt` with one entry's bytes edited (sizes unchanged; CRCs recomputed unless the edit says otherwise)."""
+    with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, "w", zipfile.ZIP_STORED) as zout:
+        for info in zin.infolist():
+            zout.writestr(info.filename, edit(info.filename, zin.read(info.filename)))
+
+
+def test_native_reader_refuses_what_it_does_not_understand(tmp_path):
+    """nothing is decoded from byte sizes alone.  Same sizes, different meaning -> not recognised (the torch.load
+    route takes the file): a float `target` storage, a transposed (non-contiguous) `prediction` is READ through its strides,
+    a payload whose CRC does not match the directory is refused, an unknown global in data.pkl is refused."""
+    src = os.path.join(PT, "chunk0", "2.pt")
+    d, want = _expect(src)
+    # (a) non-contiguous prediction written by torch.save of a permuted view: same bytes count, different strides
+    perm = dict(d)
+    perm["prediction"] = d["prediction"].permute(2, 0, 1).contiguous().permute(1, 2, 0)
+    assert not perm["prediction"].is_contiguous()
+    torch.save(perm, tmp_path / "strided.pt")
+    store = rs_api.LabelStore.load([str(tmp_path / "strided.pt")], threads=1)
+    assert store.fallback_files == []
+    for rid, (lab, _t) in want.items():
+        k = store.index[rid]
+        assert np.array_equal(store.labels[store.offsets[k]: store.offsets[k + 1]], lab), rid
+    # (b) target stored as float64: the byte size of an int64 target, refused natively, read by the fallback
+    flt = dict(d)
+    flt["target"] = d["target"].to(torch.float64)
+    torch.save(flt, tmp_path / "float_target.pt")
+    store = rs_api.LabelStore.load([str(tmp_path / "float_target.pt")], threads=1)
+    assert [os.path.basename(f) for f in store.fallback_files] == ["float_target.pt"]
+    # (c) a flipped payload byte under an unchanged directory CRC
+    raw = bytearray(open(src, "rb").read())
+    with zipfile.ZipFile(src) as z:
+        info = next(i for i in z.infolist() if i.filename.endswith("/data/0"))
+    raw[info.header_offset + 4096] ^= 0x40
+    (tmp_path / "crc.pt").write_bytes(bytes(raw))
+    store = rs_api.LabelStore.load([str(tmp_path / "crc.pt")], threads=1)
+    assert [os.path.basename(f) for f in store.fallback_files] == ["crc.pt"] and len(store) == 0
+    # (d) data.pkl naming a class this reader does not know
+    _rewrite(src, tmp_path / "glob.pt", lambda name, b: b.replace(b"torch\nLongStorage", b"torch\nHalfStorage") if name.endswith("data.pkl") else b)
+    store = rs_api.LabelStore.load([str(tmp_path / "glob.pt")], threads=1)
+    assert [os.path.basename(f) for f in store.fallback_files] == ["glob.pt"]
+
+
+def test_storage_offset_and_shared_storage(tmp_path):
+    """Tensors that are views into one larger storage (non-zero storage offset): read where the pickle says they are."""
+    src = os.path.join(PT, "chunk1", "1.pt")
+    d, want = _expect(src)
+    big = torch.cat([torch.full((7,), 3, dtype=d["target"].dtype), d["target"].reshape(-1)])
+    v = dict(d)
+    v["target"] = big[7:].view(d["target"].shape)
+    assert v["target"].storage_offset() == 7
+    torch.save(v, tmp_path / "offset.pt")
+    store = rs_api.LabelStore.load([str(tmp_path / "offset.pt")], threads=1)
+    assert store.fallback_files == []
+    for rid, (lab, _t) in want.items():
+        k = store.index[rid]
+        assert np.array_equal(store.labels[store.offsets[k]: store.offsets[k + 1]], lab), rid
