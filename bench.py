@@ -170,6 +170,10 @@ def cpu_baseline_all_cores(best_threads: int, read_len: int, budget_s: float):
     layout = {"processes": n_proc, "threads_per_process": best_threads, "usable_cpus": usable, "affinity_cpus": len(allowed),
               "cgroup_cpu_quota": placement.cpu_quota()}
     if n_proc == 1:
+        q = placement.cpu_quota()
+        layout["reason"] = (f"cgroup quota {q:g} of {os.cpu_count()} CPUs: one {best_threads}-thread process already uses the job's whole allowance"
+                            if q is not None and q < len(allowed) else
+                            f"{usable} usable CPUs hold one {best_threads}-thread process")
         return None, layout
     ctx = mp.get_context("spawn")  # fresh interpreters: nothing that has initialised the GPU is forked
     procs, conns = [], []
@@ -237,6 +241,12 @@ def main():
                     "default batching (-b 12, left-padded batches)")
     ap.add_argument("--c4-reads", type=int, default=40_000)
     ap.add_argument("--c5-reads", type=int, default=300_000)
+    ap.add_argument("--c3-file-reads", type=int, default=200_000, help="N = 1: reads of the file-fed 2 kb leg `configs.c3_2kb_file` (0 = skip)")
+    ap.add_argument("--multi-legs", default="c3,c5", help="N > 1: file-fed legs run by all ranks -> `multi_gpu.*` ('' = none): c3 = one 2 kb "
+                    "FASTQ in byte-range shards, c5 = one .fastq.gz through the node's single inflater + the same reads as BGZF shards, "
+                    "both -> chopped BGZF spliced in input order (tools/bench_multi.py)")
+    ap.add_argument("--c3-reads-per-rank", type=int, default=60_000)
+    ap.add_argument("--c5-reads-per-rank", type=int, default=75_000)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -358,6 +368,25 @@ def main():
                   "ms_per_step": round(dt / args.strict_steps * 1e3, 3)}
         model.net.set_gemm_mode(args.gemm_mode)
 
+    # N > 1: the flows in which eight GPUs can fail to scale (the host is the limiter) -- file-fed, run by ALL ranks,
+    # reported beside the resident headline, never `value` (tools/bench_multi.py)
+    multi = None
+    if world > 1 and args.multi_legs:
+        from tools import bench_multi
+
+        my_cpus = placed and placed["cpuset"]
+        multi = {}
+        wanted = [x for x in args.multi_legs.split(",") if x]
+        if "c3" in wanted:
+            leg = bench_multi.c3_sharded_leg(pipe, sd, rank, world, args.c3_reads_per_rank, cpuset=my_cpus)
+            if rank == 0:
+                multi["c3_2kb_file_sharded"] = leg
+        if "c5" in wanted:
+            legs5 = bench_multi.c5_legs(rank, world, args.c5_reads_per_rank, threads=4, cpuset=my_cpus,
+                                        keep_dir=os.environ.get("DC_BENCH_KEEP_DIR") or None)
+            if rank == 0:
+                multi.update(legs5 or {})
+
     if rank == 0:
         tokens_per_launch = B * (L + 1)
         stages = {}
@@ -418,7 +447,12 @@ def main():
                    # the same oracle, read-sharded over every CPU this job may use (processes x threads below); None when
                    # that is one process, i.e. `value` already uses them all.  A baseline, never credit.
                    "value_all_cores": None if all_rate is None else round(all_rate, 3), "all_cores_layout": layout,
-                   "thread_probe_reads_per_s": {str(k): v for k, v in probe.items()}, "host_cores": os.cpu_count(),
+                   # thread-count SELECTION only: one 12-read batch per setting, right after the warm-up -- not a sustained rate
+                   # (r05: 45.95 on the probe, 36.25 sustained at the same 16 threads); `value` is the sustained sample
+                   "thread_probe_one_batch_reads_per_s": {str(k): v for k, v in probe.items()},
+                   "value_is": "sustained: every sampled read after the warm-up and the probe, timed as one run" if n_done > 12 else
+                               "the probe's best (the budget allowed no sustained sample)",
+                   "host_cores": os.cpu_count(),
                    "reference_prose_cpu_reads_per_s": [46, 139],  # docs/faq.md:78-80 (2-6 h per 1 M reads), context only
                    "note": "CPU restatement (oracle/), not the reference binary: its backbone cannot be loaded here (SURVEY 8c)"}
             # per-base F1 of the GPU labels against the oracle's on the sampled reads (expected 1.0)
@@ -460,6 +494,12 @@ def main():
                                           "configs[0]: 1 000 synthetic 512-bp reads = one step (the whole config), HBM-resident")
                 configs["c1_512bp"]["batch_4096"] = leg(bench_legs.resident_leg, pipe, sd, 4096, 512, 10,
                                                         "512-bp reads in batches of 4 096 (the shape's best batch)", check_reads=0)
+                if cpu is not None:  # the CPU restatement on C1 as well, same thread layout as the C2 figure
+                    configs["c1_512bp"]["cpu_baseline"] = leg(bench_legs.cpu_baseline_leg, sd, 512, cpu["cores"], min(8.0, args.cpu_seconds))
+            if "c3" in legs and args.c3_file_reads > 0:
+                from tools import bench_multi
+
+                configs["c3_2kb_file"] = leg(bench_multi.c3_sharded_leg, pipe, sd, 0, 1, args.c3_file_reads)
             if "c3" in legs:
                 configs["c3_2kb_1gpu_slice"] = leg(
                     bench_legs.resident_leg, pipe, sd, 1024, 2000, 12,
@@ -499,6 +539,7 @@ def main():
             "bf16x6_leg": strict,
             "file_e2e": e2e,
             "configs": configs or None,
+            "multi_gpu": multi,
             "per_rank_seconds": per_rank_s,
             "per_rank_cpuset": cpusets,
             "cpu_budget": placed and {"cpus_worth_of_time": placed.get("cpu_budget"), "slices_cut_to_it": placed.get("capped_to_budget")},

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "dc_fq_read_chunk_full": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
     "dc_fq_records_read": (i64, [vp]),
     "dc_fq_set_strict": (C.c_int, [vp, C.c_int]),
+    "dc_fq_helper_cpu_seconds": (C.c_double, [vp]),
     "dc_fq_bytes_consumed": (i64, [vp]),
     "dc_fq_close": (None, [vp]),
     "dc_bgzf_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),

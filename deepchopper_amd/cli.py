@@ -159,56 +159,169 @@ def _launch_workers(args, argv: list[str]) -> int:
     return 0
 
 
-def _merge_under_external_launcher(args, rank: int, world: int, parts: list[str], n_reads: int, n_records: int,
-                                   interleaved: bool) -> None:
-    """`--chop` under torch.distributed.run (no parent of ours to merge): the ranks meet on a gloo group -- control
-    plane only, a barrier and one gathered tuple -- and rank 0 splices the parts exactly as the self-launching parent
-    does.  Without this every rank would leave a partial file that looks complete."""
+def predict_chop_as_external_rank(data_path: str, pipe, rank: int, world: int, *, chop_type: str = "all", chop_output: str | None = None,
+                                  threads: int = 4, ocq: bool = False, max_reads: int = 8192, max_tokens: int = 2_000_000,
+                                  reference_batch: int | None = None, max_sample: int | None = None, limit: int | None = None,
+                                  single_inflater: bool = True, quiet: bool = False) -> dict:
+    """`predict --chop` as ONE RANK of a job an external launcher started (torch.distributed.run, srun, mpirun: the ranks are
+    siblings, there is no parent of ours to feed them or to merge).  The ranks meet on a gloo group -- control plane only: a
+    few small objects and barriers -- and
+
+    * input.  Uncompressed / BGZF: every rank reads its own contiguous byte range (`rank_chunks`).  One plain gzip stream
+      (or --max-sample, which needs global record numbers) has one entry point: rank 0 runs the node's SINGLE inflater
+      (`launcher.ChunkFeeder` on named FIFOs in a directory announced over the group, bound to the CPUs the placement plan keeps
+      for a parent) and deals the chunks round-robin to every rank, itself included -- as the command's own parent does for
+      its children.  (Rounds 2-5: every rank inflated the whole file and kept every world-th chunk: N x the inflate CPU.
+      `single_inflater=False` keeps that form: A/B and the fallback where FIFOs cannot be made.)
+    * output.  Every rank writes its BGZF part; rank 0 splices them in input order (`chop.merge_bgzf_parts`) exactly as the
+      self-launching parent does, names the result and prints it; every rank learns the outcome.
+
+    Returns this rank's report: reads / records (own and total), the final path (rank 0), CPU seconds of the pipe reads and
+    of the feeder.  The reference's flow being replaced: deepchopper/cli.py:126-152 (Lightning read-sharding) followed by
+    src/bin/predict.rs:275-316 (the chop driver's chunked loop)."""
+    import datetime
+    import shutil
+    import tempfile
+
     import torch.distributed as dist
 
     from . import chop as chop_mod
+    from . import launcher, placement
 
     own = not dist.is_initialized()
     if own:  # gloo announces its connections on stdout, which carries the output path: point fd 1 at stderr meanwhile
-        import datetime
-
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            # a rank that died in predict_chop never arrives: do not wait gloo's default 30 minutes for it under a launcher
-            # that leaves the siblings alone (srun, mpirun); bench.py bounds the same barrier pattern the same way
+            # a rank that died never arrives: do not wait gloo's default 30 minutes for it under a launcher that leaves the
+            # siblings alone (srun, mpirun); bench.py bounds the same barrier pattern the same way
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
             dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    kind = check_compressed_type(data_path)
+    dealt = kind not in ("Uncompress", "Bgzip") or max_sample is not None
+    chunk_reads, chunk_bases = (reference_batch, 1 << 30) if reference_batch else (max_reads, max_tokens)
+    base = os.path.join(os.path.dirname(chop_mod._temp_name(data_path, chop_output)),
+                        f".deepchopper_temp_job{os.environ.get('MASTER_PORT', '0')}.fq.gz")
+    parts = [f"{base}.rank{r}" for r in range(world)]
+    report = {"rank": rank, "dealt": dealt, "input": "byte-range shards"}
+    feeder = pipe_src = fifo_dir = drain = None
     failure = None
     try:
+        if dealt and single_inflater:
+            box = [None]
+            if rank == 0:
+                try:
+                    fifo_dir = tempfile.mkdtemp(prefix=".deepchopper_feed_", dir=os.path.dirname(base) or ".")
+                    cpus = None
+                    try:
+                        share = os.environ.get("DC_SHARE_GPU") == "1" or os.environ.get("DC_BENCH_SHARE_GPU") == "1"
+                        lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+                        plan = placement.plan(lws, local_devices=[0] * lws if share else None) if placement.enabled() else None
+                        cpus = plan["parent"]["cpus"] if plan and plan.get("parent") else None
+                    except Exception:
+                        cpus = None
+                    feeder = launcher.ChunkFeeder(data_path, world, chunk_reads, chunk_bases, full_header=True, max_sample=max_sample,
+                                                  fifo_paths=[os.path.join(fifo_dir, f"rank{r}.fifo") for r in range(world)], cpus=cpus)
+                    box[0] = fifo_dir
+                    report["feeder_cpuset"] = placement.format_cpulist(cpus) if cpus else None
+                except OSError:  # no FIFOs on this file system: every rank inflates for itself
+                    feeder = None
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                if feeder is not None:
+                    feeder.start()
+                pipe_src = launcher.open_fifo(os.path.join(box[0], f"rank{rank}.fifo"))
+                report["input"] = "single inflater (rank 0) + FIFOs"
+        if pipe_src is not None:
+            chunks = iter(pipe_src)
+        else:
+            if dealt:
+                report["input"] = "every rank inflates the stream and keeps every world-th chunk"
+            chunks = rank_chunks(data_path, rank, world, chunk_reads, chunk_bases, max_sample, full_header=True)
+        chunks = limit_batches(chunks, limit)
+        ref_kw = {"max_reads": max_reads, "max_tokens": max_tokens}
+        if reference_batch:
+            ref_kw.update({"reference_batch": reference_batch, "mark_sub_batches": dealt})
+        n_reads = n_records = 0
+        import time
+
+        t_stream = time.perf_counter()
+        try:
+            _, n_reads, n_records = chop_mod.predict_chop(data_path, pipe, chop_type, chop_output, threads, ocq, chunks=chunks,
+                                                          part_path=parts[rank], **ref_kw)
+            report["stream_s"] = round(time.perf_counter() - t_stream, 3)  # this rank's reads: first chunk in -> BGZF part closed
+            if pipe_src is not None:
+                for _ in pipe_src:  # (--limit-batches: drain what the feeder still deals this rank, or its writer blocks)
+                    pass
+        except Exception as e:  # this rank must still reach the rendezvous below, or the others wait out the timeout
+            failure = e
+            if pipe_src is not None:  # ... and must not leave its share of the deal unread: the feeder's writer for this rank
+                import threading      # would block on a full FIFO and, behind it, every other rank's supply.  (Not close():
+                                      # a writer still waiting to open its end would wait for a reader that is gone.)
+                def _discard(src=pipe_src):
+                    try:
+                        for _ in src:
+                            pass
+                    except Exception:
+                        pass
+
+                drain = threading.Thread(target=_discard, daemon=True)
+                drain.start()
+        if feeder is not None:
+            try:
+                feeder.join()
+                report["feeder_cpu_s"] = round(feeder.cpu_s, 3)
+            except Exception as e:
+                failure = failure or e
         counts = [None] * world
-        dist.all_gather_object(counts, (n_reads, n_records))
-        if rank == 0:
+        dist.all_gather_object(counts, (n_reads, n_records, None if failure is None else f"{type(failure).__name__}: {failure}"))
+        bad = [(r, c[2]) for r, c in enumerate(counts) if c[2] is not None]
+        final = None
+        if rank == 0 and not bad:
             try:
                 tot_r, tot_o = sum(c[0] for c in counts), sum(c[1] for c in counts)
                 if tot_r == 0:
-                    raise ValueError(f"No valid records found in {args.data_path}")
-                final = chop_mod._final_name(str(args.data_path), args.chop_output, tot_r, tot_o)
-                chop_mod.merge_bgzf_parts(parts, final, interleaved=interleaved)
-                print(final)
-            except Exception as e:  # rank 0 must still reach the rendezvous below, or the others wait out the timeout
+                    raise ValueError(f"No valid records found in {data_path}")
+                final = chop_mod._final_name(data_path, chop_output, tot_r, tot_o)
+                t_merge = time.perf_counter()
+                chop_mod.merge_bgzf_parts(parts, final, interleaved=dealt)
+                report["merge_s"] = round(time.perf_counter() - t_merge, 3)
+                if not quiet:
+                    print(final)
+            except Exception as e:
                 failure = e
         verdict = [None if failure is None else f"{type(failure).__name__}: {failure}"]
         dist.broadcast_object_list(verdict, src=0)  # doubles as the final barrier; every rank learns the outcome
-        if verdict[0] is not None and rank != 0:
+        if failure is None and bad:
+            failure = RuntimeError(f"rank {bad[0][0]} failed: {bad[0][1]}")
+        if failure is None and verdict[0] is not None:
             failure = RuntimeError(f"rank 0 could not merge the per-rank outputs: {verdict[0]}")
+        report.update({"reads": n_reads, "records": n_records, "total_reads": sum(c[0] for c in counts),
+                       "total_records": sum(c[1] for c in counts), "final": final})
+        if pipe_src is not None:
+            report.update({"pipe_read_cpu_s": round(pipe_src.cpu_s, 3), "pipe_bytes": pipe_src.bytes})
     finally:
+        if drain is not None:
+            drain.join(timeout=30)  # (the feeder has closed its ends by the time the rendezvous above is through)
+        if pipe_src is not None:
+            try:
+                pipe_src.close()
+            except Exception:
+                pass
         if rank == 0:
             chop_mod.remove_parts(parts)
+            if fifo_dir:
+                shutil.rmtree(fifo_dir, ignore_errors=True)
         if own:
             dist.destroy_process_group()
     if failure is not None:
         raise failure  # every rank exits non-zero
+    return report
 
 
 def _predict(args, argv: list[str]) -> int:
@@ -284,16 +397,13 @@ def _predict(args, argv: list[str]) -> int:
         if args.part_path:  # worker of a multi-GPU run: the parent splices the parts and names the result
             _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                  args.ocq, chunks=chunks, part_path=args.part_path, **ref_kw)
-        elif world > 1:  # external launcher (torch.distributed.run): parts on a name all ranks can derive, rank 0 merges
-            from .chop import _temp_name
-
-            base = os.path.join(os.path.dirname(_temp_name(str(data_path), args.chop_output)),
-                                f".deepchopper_temp_job{os.environ.get('MASTER_PORT', '0')}.fq.gz")
-            parts = [f"{base}.rank{r}" for r in range(world)]
-            _, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
-                                                 args.ocq, chunks=chunks, part_path=parts[rank], **ref_kw)
-            dealt = check_compressed_type(str(data_path)) not in ("Uncompress", "Bgzip") or args.max_sample is not None
-            _merge_under_external_launcher(args, rank, world, parts, n_reads, n_records, dealt)
+        elif world > 1:  # external launcher (torch.distributed.run): single inflater on rank 0 / byte-range shards, rank 0 merges
+            ext = predict_chop_as_external_rank(str(data_path), pipe, rank, world, chop_type=args.chop_type, chop_output=args.chop_output,
+                                                threads=args.threads, ocq=args.ocq, max_reads=args.max_reads, max_tokens=args.max_tokens,
+                                                reference_batch=max_reads if args.reference_batching else None,
+                                                max_sample=args.max_sample, limit=args.limit_batches,
+                                                single_inflater=os.environ.get("DC_SINGLE_INFLATER", "1") != "0")
+            n_reads, n_records = ext["reads"], ext["records"]
         else:
             final, n_reads, n_records = predict_chop(str(data_path), pipe, args.chop_type, args.chop_output, args.threads,
                                                      args.ocq, chunks=chunks, **ref_kw)

@@ -108,8 +108,9 @@ class ParInflate {
   static constexpr uint64_t NONE = ~0ull;
   static constexpr int TRIAL = 2048;
 
-  ParInflate(const uint8_t* origin, const uint8_t* end, int threads, size_t chunk_bytes, std::function<bool()> cancelled)
-      : origin_(origin), end_(end), chunk_bytes_(chunk_bytes), cancelled_(std::move(cancelled)) {
+  ParInflate(const uint8_t* origin, const uint8_t* end, int threads, size_t chunk_bytes, std::function<bool()> cancelled,
+             std::atomic<int64_t>* cpu_ns = nullptr)
+      : origin_(origin), end_(end), chunk_bytes_(chunk_bytes), cancelled_(std::move(cancelled)), cpu_ns_(cpu_ns) {
     total_bits_ = (uint64_t)(end - origin) * 8;
     n_ = (int)(((size_t)(end - origin) + chunk_bytes - 1) / chunk_bytes);
     starts_.assign((size_t)n_ + 1, NONE);
@@ -117,7 +118,16 @@ class ParInflate {
     chunks_.resize((size_t)n_);
     ready_.assign((size_t)n_, 0);
     window_ = 2 * threads + 1;
-    for (int t = 0; t < threads; ++t) workers_.emplace_back([this] { work(); });
+    for (int t = 0; t < threads; ++t)
+      workers_.emplace_back([this] {
+        work();
+        if (cpu_ns_) cpu_ns_->fetch_add(thread_cpu_ns());  // (a worker lives for one member: its whole CPU time is inflate)
+      });
+  }
+  static int64_t thread_cpu_ns() {
+    timespec t;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+    return (int64_t)t.tv_sec * 1000000000ll + t.tv_nsec;
   }
   ~ParInflate() {
     {
@@ -174,6 +184,7 @@ class ParInflate {
   const uint8_t* end_;
   size_t chunk_bytes_;
   std::function<bool()> cancelled_;
+  std::atomic<int64_t>* cpu_ns_ = nullptr;
   uint64_t total_bits_ = 0;
   int n_ = 0, next_ = 0, released_ = 0, window_ = 0;
   std::atomic<bool> stop_{false};  // set by the destructor; scan() and decode() poll it so that speculative work past the
@@ -297,6 +308,7 @@ struct Source {
   std::string err;
   std::atomic<int64_t> consumed{0};
   std::atomic<bool> fast_crc{false};  // blocks come from the in-house inflater: the consumer keeps the running CRC-32
+  std::atomic<int64_t> helper_cpu_ns{0};  // CPU time of the reading / inflating threads that have finished (dc_fq_helper_cpu_seconds)
   // BGZF byte-range shards: compressed offset the stream starts at / the block boundary that ends the
   // range; range_end_u = (decompressed bytes emitted up to that boundary) + 1, published once reached
   int64_t start_off = 0, end_off = INT64_MAX;
@@ -445,7 +457,7 @@ struct Source {
   // cancelled; otherwise trailer points at the member's CRC-32 / ISIZE.
   bool inflate_member_parallel(const uint8_t* q, const uint8_t* fend, int threads, size_t chunk_bytes, uint64_t& member_out,
                                const uint8_t*& trailer, int64_t& pushed, std::string& e) {
-    ParInflate par(q, fend, threads, chunk_bytes, [this] { return cancelled(); });
+    ParInflate par(q, fend, threads, chunk_bytes, [this] { return cancelled(); }, &helper_cpu_ns);
     std::vector<uint8_t> win;  // last <= 32 KiB of this member's output
     std::vector<uint8_t> tab(256 + 32768);
     for (int k = 0; k < 256; ++k) tab[(size_t)k] = (uint8_t)k;
@@ -700,6 +712,10 @@ struct Source {
 
   void start() {
     th = std::thread([this] {
+      struct Account {  // this thread's CPU time, added when it ends (whichever way it returns)
+        std::atomic<int64_t>& to;
+        ~Account() { to.fetch_add(ParInflate::thread_cpu_ns()); }
+      } account{helper_cpu_ns};
       if (!compressed) return run_plain();
       const char* sel = getenv("DC_IO_INFLATE");
       if (sel && strcmp(sel, "zlib") == 0) return run_gzip();
@@ -919,6 +935,7 @@ int dc_fq_set_strict(dc_fq_reader* r, int strict_four_line) {
   return 0;
 }
 int64_t dc_fq_bytes_consumed(const dc_fq_reader* r) { return r ? r->src.consumed.load() : 0; }
+double dc_fq_helper_cpu_seconds(const dc_fq_reader* r) { return r ? 1e-9 * (double)r->src.helper_cpu_ns.load() : 0.0; }
 void dc_fq_close(dc_fq_reader* r) { delete r; }
 
 // name_len == nullptr: `names` receives the name part of every definition line (up to the first blank or

@@ -179,6 +179,11 @@ class FastqReader:
     def bytes_consumed(self) -> int:
         return int(_iolib.lib().dc_fq_bytes_consumed(self._h)) if self._h else 0
 
+    @property
+    def helper_cpu_seconds(self) -> float:
+        """CPU seconds of the reader's finished helper threads (read-ahead, inflate): exact once the stream is exhausted."""
+        return float(_iolib.lib().dc_fq_helper_cpu_seconds(self._h)) if self._h else 0.0
+
     def close(self) -> None:
         if self._h:
             _iolib.lib().dc_fq_close(self._h)

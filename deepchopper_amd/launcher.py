@@ -225,27 +225,57 @@ class PipeChunks:
 
 
 class ChunkFeeder:
-    """Parent side: parse `path` once and deal its chunks round-robin to `world` pipes.  One writer thread per
-    pipe with a short queue, so a worker that is momentarily busy does not stall the others' supply."""
+    """The node's single reader / inflater: parse `path` once and deal its chunks round-robin to `world` pipes.  One writer
+    thread per pipe with a short queue, so a worker that is momentarily busy does not stall the others' supply.
+
+    Two transports.  Anonymous pipes (default): the command's own parent creates them and its workers inherit the read ends
+    (`read_fds`).  Named FIFOs (`fifo_paths`): ranks started by an EXTERNAL launcher (torch.distributed.run) are siblings, not
+    children -- rank 0 runs the feeder on FIFOs in a directory all ranks learn over the control plane, and every rank (rank 0
+    included) opens its own with `open_fifo`.  `cpus`: CPUs for the feeder's threads (and the native inflate threads they
+    start) -- under an external launcher rank 0 is a GPU worker with its own slice; the feeder takes the slice the plan keeps
+    for a parent.  `cpu_s`: CPU seconds of the feeder's threads incl. the reader's native helpers, after join()."""
 
     def __init__(self, path: str, world: int, max_reads: int, max_bases: int, *, full_header: bool = False,
-                 max_sample: int | None = None, depth: int = 3):
+                 max_sample: int | None = None, depth: int = 3, fifo_paths: list[str] | None = None, cpus: list[int] | None = None):
         import queue
 
         self.path, self.world = path, world
         self.max_reads, self.max_bases, self.full_header, self.max_sample = max_reads, max_bases, full_header, max_sample
-        pipes = [os.pipe() for _ in range(world)]
-        self.read_fds = [r for r, _ in pipes]
-        self._write_fds = [w for _, w in pipes]
-        for r in self.read_fds:
-            os.set_inheritable(r, True)
+        self.fifo_paths = fifo_paths
+        self.cpus = list(cpus) if cpus else None
+        if fifo_paths is None:
+            pipes = [os.pipe() for _ in range(world)]
+            self.read_fds = [r for r, _ in pipes]
+            self._write_fds = [w for _, w in pipes]
+            for r in self.read_fds:
+                os.set_inheritable(r, True)
+        else:
+            assert len(fifo_paths) == world
+            for f in fifo_paths:
+                os.mkfifo(f, 0o600)
+            self.read_fds, self._write_fds = [], [None] * world  # (a FIFO's write end opens once its reader has: in the writer thread)
         self._queues = [queue.Queue(maxsize=depth) for _ in range(world)]
         self._threads: list[threading.Thread] = []
         self.error: BaseException | None = None
         self.n_reads = 0
+        self.cpu_s = 0.0
+        self._cpu_lock = threading.Lock()
+
+    def _enter_thread(self) -> None:
+        if self.cpus and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, self.cpus)  # (pid 0 = the calling THREAD; threads it starts inherit the mask)
+            except OSError:
+                pass
+
+    def _leave_thread(self, extra: float = 0.0) -> None:
+        import time
+
+        with self._cpu_lock:
+            self.cpu_s += time.thread_time() + extra
 
     def start(self) -> None:
-        """Call after the workers have been spawned (they inherited the read ends)."""
+        """Call after the workers have been spawned (they inherited the read ends) / after the FIFOs' directory was announced."""
         for r in self.read_fds:
             os.close(r)
         for i in range(self.world):
@@ -257,7 +287,9 @@ class ChunkFeeder:
         self._threads.append(t)
 
     def _reader(self):
+        helpers = 0.0
         try:
+            self._enter_thread()
             seen = 0
             with FastqReader(self.path, full_header=self.full_header) as rd:
                 for i, c in enumerate(rd.chunks(self.max_reads, self.max_bases)):
@@ -270,15 +302,20 @@ class ChunkFeeder:
                         self._queues[i % self.world].put(own)
                     if self.max_sample is not None and seen >= self.max_sample:
                         break
+                helpers = rd.helper_cpu_seconds  # (complete when the stream was read to its end; a --max-sample cut-off under-counts)
             self.n_reads = seen
         except BaseException as e:
             self.error = e
         finally:
+            self._leave_thread(helpers)
             for q in self._queues:
                 q.put(None)
 
     def _writer(self, i: int):
         try:
+            self._enter_thread()
+            if self._write_fds[i] is None:
+                self._write_fds[i] = self._open_fifo_for_writing(self.fifo_paths[i])
             with os.fdopen(self._write_fds[i], "wb", buffering=1 << 20) as fh:
                 while True:
                     c = self._queues[i].get()
@@ -292,12 +329,43 @@ class ChunkFeeder:
                 pass
         except BaseException as e:
             self.error = self.error or e
+        finally:
+            self._leave_thread()
+
+    @staticmethod
+    def _open_fifo_for_writing(path: str, patience_s: float = 600.0) -> int:
+        """A FIFO's write end opens once its reader has opened the other: wait for the rank, but not for ever (a rank that
+        died before it got here would otherwise hang the feeder and, behind it, everyone's final rendezvous)."""
+        import errno
+        import time
+
+        deadline = time.monotonic() + patience_s
+        while True:
+            try:
+                fd = os.open(path, os.O_WRONLY | os.O_NONBLOCK)
+                os.set_blocking(fd, True)
+                return fd
+            except OSError as e:
+                if e.errno != errno.ENXIO or time.monotonic() > deadline:
+                    raise
+                time.sleep(0.01)
 
     def join(self) -> None:
         for t in self._threads:
             t.join()
+        if self.fifo_paths:
+            for f in self.fifo_paths:
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
         if self.error is not None:
             raise self.error
+
+
+def open_fifo(path: str) -> "PipeChunks":
+    """Worker side of a FIFO-fed run: this rank's end of the feeder's FIFO (blocks until the feeder has opened its end)."""
+    return PipeChunks(os.open(path, os.O_RDONLY))
 
 
 def worker_python() -> list[str]:

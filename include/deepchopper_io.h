@@ -96,6 +96,11 @@ int dc_fq_read_chunk_full(dc_fq_reader* r, int64_t max_reads, uint8_t* seq, uint
 /* records delivered so far / compressed-or-plain bytes consumed so far */
 int64_t dc_fq_records_read(const dc_fq_reader* r);
 
+/* CPU seconds of the reader's helper threads -- file read-ahead, gzip / BGZF inflate incl. the parallel single-member
+ * decoder -- that have FINISHED (exact once the stream is exhausted; a thread still running is not counted yet).  Host-budget
+ * accounting of the node's single inflater (bench.py --gpus N, tools/host_budget.py); no reference equivalent. */
+double dc_fq_helper_cpu_seconds(const dc_fq_reader* r);
+
 /* Record grammar.  Default (0): what kseq accepts -- `predict` reads with pyfastx.Fastx (deepchopper/data/only_fq.py:34):
  * sequence and quality may wrap over several lines.  strict_four_line = 1: exactly four lines per record, what noodles'
  * fastq reader accepts -- the reference's `chop` reads with it (src/output/writefq.rs:172-199, src/bin/predict.rs:275-316):

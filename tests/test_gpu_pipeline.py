@@ -624,6 +624,61 @@ def test_multi_rank_chop_output_is_in_input_order_and_byte_identical_to_one_gpu(
     assert left == [], left
 
 
+@pytest.mark.parametrize("launch", ["self", "torchrun"])
+def test_bench_two_rank_file_legs_match_one_gpu_bytes(hip_lib, tmp_path, launch):
+    """`bench.py --gpus 2` carries file-fed legs beside the resident headline -- c3 (one 2 kb FASTQ in
+    byte-range shards), c5 (one .fastq.gz through the node's single inflater; the same reads as BGZF shards) -- with per-rank
+    reads/s, CPU seconds per 1 000 reads and one host_bound verdict each; and the N = 2 c5 output IS the file `-g 1` writes:
+    byte for byte for the dealt gzip stream, record for record for the BGZF shards.  Ranks share this box's one GPU."""
+    import gzip
+    import json
+
+    from deepchopper_amd.weights import save_state_dict, token_gated_state_dict
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    keep = tmp_path / "keep"
+    envv = dict(os.environ, DC_BENCH_SHARE_GPU="1", DC_BENCH_KEEP_DIR=str(keep), DC_BENCH_TIMEOUT="500")
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256", "--strict-steps", "0", "--no-profile",
+            "--c3-reads-per-rank", "3000", "--c5-reads-per-rank", "5000"]
+    if launch == "self":
+        cmd = [sys.executable, "bench.py"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29641", "bench.py"] + args
+    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=560, env=envv)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = json.loads([l for l in proc.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    legs = line["multi_gpu"]
+    assert set(legs) == {"c3_2kb_file_sharded", "c5_gz_single_inflater", "c5_bgzf_sharded"}, legs
+    for name, leg in legs.items():
+        assert "error" not in leg, (name, leg)
+        assert len(leg["per_rank"]) == 2 and all(r["reads"] > 0 and r["reads_per_s"] > 0 for r in leg["per_rank"])
+        assert leg["host"]["cpu_budget_cores"] >= 1 and isinstance(leg["host"]["host_bound"], bool)
+        assert leg["cpu_s_per_1000_reads"]["worker"] > 0
+        assert all(v is True for k, v in leg["check"].items() if isinstance(v, bool)), (name, leg["check"])
+    c3 = legs["c3_2kb_file_sharded"]
+    assert c3["reads"] == 6000 and [r["reads"] for r in c3["per_rank"]] == [3000, 3000]
+    assert c3["check"]["per_base_f1_vs_oracle"] == 1.0 and c3["check"]["intervals_identical"]
+    gzl, bgl = legs["c5_gz_single_inflater"], legs["c5_bgzf_sharded"]
+    assert gzl["input"].startswith("single inflater") and gzl["cpu_s_per_1000_reads"]["parent"] > 0
+    assert gzl["reads"] == bgl["reads"] == 10000 and gzl["check"]["head_bytes_identical"]
+    # ... and `-g 1` on the very same input
+    tmp = next(keep.iterdir())
+    ckpt = tmp_path / "ckpt" / "model.safetensors"
+    save_state_dict(token_gated_state_dict(0), str(ckpt))
+    one = subprocess.run([sys.executable, "-m", "deepchopper_amd.cli", "predict", str(tmp / "hct116_like.fastq.gz"), "--chop", "-g", "1",
+                          "-m", str(ckpt.parent), "-t", "4", "--chop-output", str(tmp_path / "one")], cwd=root, capture_output=True,
+                         text=True, timeout=300, env=dict(os.environ))
+    assert one.returncode == 0, one.stderr[-3000:]
+    one_path = [l for l in one.stdout.strip().splitlines() if l.endswith(".chop.fq.gz")][-1]
+    a, b, c = open(one_path, "rb").read(), open(gzl["output"], "rb").read(), open(bgl["output"], "rb").read()
+    assert os.path.basename(one_path).split(".", 1)[1] == os.path.basename(gzl["output"]).split(".", 1)[1]
+    assert a == b, "the dealt single-inflater output must be the file one GPU writes, byte for byte"
+    assert gzip.decompress(a) == gzip.decompress(c), "the BGZF-sharded output must hold the same records in the same order"
+    assert gzl["records_out"] == bgl["records_out"]
+
+
 def test_results_do_not_depend_on_a_handles_history_or_stream(env, tmp_path):
     """Two properties the round-3 "lanes" experiment (several model handles on several HIP streams) exposed:
     (1) a read's logits must not depend on what its handle processed before -- the fp16x3 scale of a channel's long filter

@@ -151,3 +151,61 @@ def test_failed_worker_is_reported(tmp_path):
     with pytest.raises(ValueError):
         launcher.last_json_line("no report here")
     assert launcher.last_json_line('x\n{"a": 1}\n') == {"a": 1}
+
+
+def test_single_inflater_over_named_fifos_for_sibling_ranks(tmp_path):
+    """Ranks an EXTERNAL launcher started are siblings: rank 0 runs the feeder on named FIFOs, every rank -- rank 0 included --
+    opens its own (launcher.open_fifo).  Same deal as over anonymous pipes: chunk g goes to rank g % W; the feeder accounts
+    the CPU of its threads and of the reader's native inflate helpers; the FIFOs are gone after join(); a rank that never
+    shows up is an error after the patience, not a hang."""
+    import threading
+
+    seqs, quals, ids = synth.synth_reads_mixed(47, 60, 700, seed=11)
+    fq = tmp_path / "reads.fastq.gz"
+    with gzip.open(fq, "wb") as fh:
+        fh.write(synth.to_fastq(seqs, quals, ids))
+    world = 3
+    fifos = [str(tmp_path / f"rank{r}.fifo") for r in range(world)]
+    allowed = sorted(os.sched_getaffinity(0))
+    feeder = launcher.ChunkFeeder(str(fq), world, max_reads=4, max_bases=5000, full_header=True, fifo_paths=fifos, cpus=allowed[:2])
+    got = [[] for _ in range(world)]
+
+    def rank(r):
+        src = launcher.open_fifo(fifos[r])
+        for c in src:
+            got[r].append(c.names())
+        src.close()
+
+    feeder.start()
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    feeder.join()
+    assert feeder.n_reads == 47 and feeder.cpu_s > 0
+    assert not any(os.path.exists(f) for f in fifos)
+    with FastqReader(str(fq)) as rd:
+        want = [c.names() for c in rd.chunks(4, 5000)]
+    for r in range(world):
+        assert got[r] == want[r::world]
+    assert [n for g in range(len(want)) for n in got[g % world][g // world]] == ids
+    # a reader that never opens its end
+    lone = str(tmp_path / "lone.fifo")
+    os.mkfifo(lone)
+    with pytest.raises(OSError):
+        launcher.ChunkFeeder._open_fifo_for_writing(lone, patience_s=0.2)
+
+
+def test_reader_accounts_its_inflate_threads(tmp_path):
+    """dc_fq_helper_cpu_seconds: the CPU the reader's helper threads (read-ahead, inflate incl. the parallel member decoder)
+    spent, exact once the stream is exhausted -- what the host-budget legs of bench.py charge the node's single inflater."""
+    seqs, quals, ids = synth.synth_reads_mixed(4000, 800, 1200, seed=5)
+    text = synth.to_fastq(seqs, quals, ids)
+    fq = tmp_path / "big.fastq.gz"
+    with gzip.open(fq, "wb", compresslevel=1) as fh:
+        fh.write(text)
+    with FastqReader(str(fq)) as rd:
+        n = sum(c.n for c in rd.chunks(1000, 1 << 22))
+        cpu = rd.helper_cpu_seconds
+    assert n == 4000 and 0.001 < cpu < 30.0, cpu

@@ -57,70 +57,81 @@ def test_single_process_helpers_are_identity():
     assert gather_results({"a": 1}) == {"a": 1}
 
 
-def _merge_rank(rank, world, port, fq_path, parts, sabotage, out_dir):
-    """A rank of `predict --chop` under an external launcher, after its predict_chop: parts written, counts known."""
-    import argparse
+def _external_rank(rank, world, port, fq_path, out_dir, mode):
+    """A rank of `predict --chop` under an external launcher (cli.predict_chop_as_external_rank) with the GPU stage replaced:
+    `predict_chop` copies the rank's chunks into its BGZF part, one block run per chunk, as the real one writes its records."""
     import json
 
+    from deepchopper_amd import chop as chop_mod
     from deepchopper_amd import cli
+    from deepchopper_amd.fastq import BgzfWriter
 
-    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
-    args = argparse.Namespace(data_path=fq_path, chop_output=os.path.join(out_dir, "merged"))
-    outcome = "ok"
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank), "LOCAL_WORLD_SIZE": str(world), "DC_SHARE_GPU": "1"})
+
+    def fake_predict_chop(fq, pipe, chop_type="all", output_prefix=None, threads=2, ocq=False, chunks=None, part_path=None, **kw):
+        if mode == "rank1_fails" and rank == 1:
+            raise RuntimeError("boom on rank 1")
+        n = 0
+        w = BgzfWriter(part_path, threads=1)
+        with w:
+            for c in chunks:
+                n += c.n
+                w.write_chunk(c)
+                w.mark()
+        chop_mod.write_part_index(part_path, w)
+        return part_path, n, n
+
+    chop_mod.predict_chop = fake_predict_chop
+    outcome = {"ok": True}
     try:
-        counts = (0, 0) if sabotage else ((3, 3) if rank == 0 else (2, 2))
-        cli._merge_under_external_launcher(args, rank, world, parts, counts[0], counts[1], interleaved=False)
+        rep = cli.predict_chop_as_external_rank(fq_path, None, rank, world, chop_output=os.path.join(out_dir, "merged"), max_reads=1,
+                                                max_tokens=1 << 20, quiet=True, single_inflater=mode != "every_rank_inflates")
+        outcome.update({k: rep.get(k) for k in ("reads", "total_reads", "input", "final", "feeder_cpu_s", "pipe_bytes")})
     except Exception as e:
-        outcome = f"{type(e).__name__}: {e}"
+        outcome = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     with open(os.path.join(out_dir, f"outcome{rank}.json"), "w") as fh:
         json.dump(outcome, fh)
 
 
-def _make_parts(tmp_path):
-    from deepchopper_amd.chop import write_part_index
-    from deepchopper_amd.fastq import BgzfWriter, FastqChunk, FastqReader
-
-    def copy(c):  # a reader's chunks share its staging buffers
-        return FastqChunk(c.n, c.seq.copy(), c.qual.copy(), c.offsets.copy(), c._names.copy(), c._name_offsets.copy(),
-                          None if c._name_len is None else c._name_len.copy())
-
-    seqs, quals, ids = synth.synth_reads_mixed(5, 60, 200, seed=4)
-    text = synth.to_fastq(seqs, quals, ids)
-    fq = tmp_path / "r.fq"
-    fq.write_bytes(text)
-    parts = []
-    with FastqReader(str(fq)) as rd:
-        chunks = [copy(c) for c in rd.chunks(1, 1 << 20)]
-        for r, sl in enumerate((slice(0, 3), slice(3, 5))):
-            parts.append(str(tmp_path / f"part.rank{r}"))
-            w = BgzfWriter(parts[-1], threads=1)
-            with w:
-                for c in chunks[sl]:
-                    w.write_chunk(c)
-                    w.mark()
-            write_part_index(parts[-1], w)
-    return str(fq), parts, text
-
-
-def test_external_launcher_merge_and_failure_reaches_every_rank(tmp_path):
-    """`predict --chop` under torch.distributed.run (cli._merge_under_external_launcher): rank 0 splices the parts; when its
-    merge fails, EVERY rank learns it at the rendezvous and raises -- nobody waits out a timeout, nothing is left behind
-    (rank 0 used to raise before the final barrier)."""
+def test_external_launcher_ranks_single_inflater_merge_and_failures(tmp_path):
+    """`predict --chop` under torch.distributed.run (cli.predict_chop_as_external_rank), two gloo ranks on CPU:
+    * an uncompressed file: byte-range shards, parts concatenated rank by rank;
+    * one gzip stream: rank 0 is the node's single inflater and deals the chunks over FIFOs to both ranks (itself included), the
+      parts are spliced chunk by chunk -- and the round 2-5 form in which every rank inflates for itself gives the same file;
+    * the merged file IS the input, in input order; nothing is left behind (parts, sidecars, FIFO directory);
+    * a rank that fails in its predict stage, or a merge that fails on rank 0 (no records), reaches EVERY rank at the rendezvous:
+      everybody raises, nobody waits out a timeout."""
     import glob
     import gzip
     import json
 
-    for sabotage in (False, True):
-        d = tmp_path / f"case{int(sabotage)}"
+    seqs, quals, ids = synth.synth_reads_mixed(9, 60, 200, seed=4)
+    text = synth.to_fastq(seqs, quals, ids)
+    for mode, name, data in (("shards", "r.fq", text), ("single_inflater", "r.fastq.gz", gzip.compress(text)),
+                             ("every_rank_inflates", "r.fastq.gz", gzip.compress(text)), ("rank1_fails", "r.fastq.gz", gzip.compress(text)),
+                             ("no_records", "r.fq", b"")):
+        d = tmp_path / mode
         d.mkdir()
-        fq, parts, text = _make_parts(d)
-        mp.spawn(_merge_rank, args=(2, _free_port(), fq, parts, sabotage, str(d)), nprocs=2, join=True)
+        fq = d / name
+        fq.write_bytes(data)
+        mp.spawn(_external_rank, args=(2, _free_port(), str(fq), str(d), mode), nprocs=2, join=True)
         outcomes = [json.load(open(d / f"outcome{r}.json")) for r in range(2)]
-        assert not any(os.path.exists(p) or os.path.exists(p + ".idx.npy") for p in parts)
+        left = [f for f in os.listdir(d) if f.startswith(".deepchopper")]
+        assert left == [], (mode, left)
         merged = glob.glob(str(d / "merged*"))
-        if sabotage:
-            assert "No valid records" in outcomes[0] and "rank 0 could not merge" in outcomes[1], outcomes
+        if mode == "rank1_fails":
+            assert [o["ok"] for o in outcomes] == [False, False] and all("boom on rank 1" in o["error"] for o in outcomes), outcomes
+            assert merged == []
+        elif mode == "no_records":
+            assert "No valid records" in outcomes[0]["error"] and "rank 0 could not merge" in outcomes[1]["error"], outcomes
             assert merged == []
         else:
-            assert outcomes == ["ok", "ok"], outcomes
-            assert len(merged) == 1 and gzip.open(merged[0], "rb").read() == text
+            assert [o["ok"] for o in outcomes] == [True, True], outcomes
+            assert sum(o["reads"] for o in outcomes) == 9 == outcomes[0]["total_reads"] and all(o["reads"] > 0 for o in outcomes)
+            assert len(merged) == 1 and merged[0] == outcomes[0]["final"] and gzip.open(merged[0], "rb").read() == text
+            want = {"shards": "byte-range shards", "single_inflater": "single inflater (rank 0) + FIFOs",
+                    "every_rank_inflates": "every rank inflates the stream and keeps every world-th chunk"}[mode]
+            assert all(o["input"] == want for o in outcomes), outcomes
+            if mode == "single_inflater":
+                assert outcomes[0]["feeder_cpu_s"] > 0 and all(o["pipe_bytes"] > 0 for o in outcomes)

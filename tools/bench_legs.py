@@ -44,6 +44,33 @@ def oracle_reads(sd, names, seqs, quals, batch: int = 12):
     return out
 
 
+def cpu_baseline_leg(sd, read_len: int, threads: int, budget_s: float) -> dict:
+    """The CPU oracle (kind "port") on reads of another length, at a given thread count: one warm-up batch of 12, then batches of
+    12 until the budget is spent -- a sustained sample, timed as one run."""
+    import torch
+
+    from deepchopper_amd import synth
+
+    n = 1200
+    seq, qual, ids = synth.synth_reads_fixed(n, read_len, seed=42)
+    seqs, quals = [seq[i].tobytes() for i in range(n)], [qual[i].tobytes() for i in range(n)]
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        oracle_reads(sd, ids[:12], seqs[:12], quals[:12])
+        t0 = time.perf_counter()
+        done = 12
+        while time.perf_counter() - t0 < budget_s and done + 12 <= n:
+            oracle_reads(sd, ids[done: done + 12], seqs[done: done + 12], quals[done: done + 12])
+            done += 12
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
+    return {"value": round((done - 12) / dt, 3), "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": f"{done - 12} synthetic {read_len}-bp reads after a 12-read warm-up, oracle tokenise + forward (torch fp32, batch 12) + smooth, "
+                      f"sustained over {dt:.1f} s"}
+
+
 def f1_check(expected: dict, got: dict) -> dict:
     """expected / got: {read id: (labels int8[n], intervals [(s, e), ...])} -> per-base F1 of label 1 and interval identity."""
     tp = fp = fn = 0
