@@ -138,8 +138,9 @@ inline constexpr FftClassInfo kFftClass[kFftClasses] = {{1024, 1, 10},  {2048, 1
                                                         {12288, 3, 12}, {16384, 4, 12}, {16384, 1, 14}, {32768, 0, 15}};
 int fft_twiddle_count();                           // float2 entries of the twiddle tables (one buffer)
 int launch_fft_twiddles(hipStream_t st, float* tw);
+int64_t hyena_fft_spec_floats(int cls, int D);     // floats of a size class's spectrum buffer (spectra + the split kernel's pair maps)
 int launch_hyena_fft_filter(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
-                            const float* tw, float* spec);  // spec: [D][points + 1] float2
+                            const float* tw, float* spec);  // spec: [D][points + 1] float2 (+ pair maps, hyena_fft_spec_floats)
 int launch_hyena_fft(hipStream_t st, const HyenaArgs& a, int cls, const int32_t* reads, int n_reads, const float* tw,
                      const float* spec);
 // reads of 16 385 .. 32 769 tokens: 2^15 complex points as 16 x 2048 (two kernels, one scratch round trip of

@@ -386,7 +386,7 @@ int ensure_fft_spectra(dc_model* m, hipStream_t st, int b) {
     if (rc) return rc;
   }
   if (m->kspec_valid[b]) return DC_OK;
-  const size_t bytes = (size_t)m->cfg.d_model * ((size_t)kFftClass[b].points + 1) * 2 * sizeof(float);
+  const size_t bytes = (size_t)hyena_fft_spec_floats(b, m->cfg.d_model) * sizeof(float);
   for (auto& L : m->layers) {
     if (!L.kspec[b]) DC_HIP_CHECK(hipMalloc((void**)&L.kspec[b], bytes));
     int rc = launch_hyena_fft_filter(st, b, L.kf, m->kf_taps, (int)m->kf_taps, m->cfg.d_model, m->fft_tw, L.kspec[b]);

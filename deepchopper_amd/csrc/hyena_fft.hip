@@ -671,11 +671,79 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16) void hyena_fftq_filter_kernel
   }
 }
 
-template <int LOGN, int Q, bool TAB, int SP>
+// ---------------------------------------------------------------------------------------------------
+// Pair maps (round 6).  Between the two transforms the packed-real convolution does, per conjugate pair (k, M - k):
+// unpack (C[k], C[M-k]) -> (Z[k], Z[M-k]), multiply by (K[k], K[M-k]), repack -> (C'[k], C'[M-k]).  All three steps are linear
+// in a = C[k], b = conj(C[M-k]), so the whole thing is ONE 2 x 2 complex map per pair.  With w = W_2M^k = c + i s,
+// P = K[k], Qc = conj(K[M-k]):
+//       u = C'[k]        = A a + B b          A  = ((P + Qc) + s (P - Qc)) / 2
+//       v = conj(C'[M-k]) = -B a + A' b       A' = ((P + Qc) - s (P - Qc)) / 2        B = i c (P - Qc) / 2
+// (alpha = (1 - i w) / 2, beta = (1 + i w) / 2: Z[k] = alpha a + beta b, conj Z[M-k] = beta a + alpha b, u = conj(alpha) P Z[k] +
+//  conj(beta) Qc conj Z[M-k], v likewise with alpha and beta swapped; |alpha|^2 = (1 + s) / 2, |beta|^2 = (1 - s) / 2,
+//  conj(alpha) beta = i c / 2.)  A, A', B are built once per filter and size class, in double, with the inverse transform's
+// 1 / M folded in; the kernel's product phase is then 8 packed FMAs per pair with no twiddle, no halving and no conjugation
+// left (round 5: 59 instructions per pair, 470 of a thread's ~2 000).  Bin 0 (Y[0] and Y[M] are real and pair with each
+// other) keeps its own two real factors in A; the self-paired middle bin has B = 0.
+// coef layout per channel: A[0 .. M/2] | A'[0 .. M/2] | B[0 .. M/2]  (float2 each).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hyena_fft_pairmap_kernel(const float2* __restrict__ spec, const float2* __restrict__ twq, int qstep,
+                                                               int M, float2* __restrict__ coef) {
+  const int kk = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  const int H = M / 2 + 1;
+  if (kk >= H) return;
+  const float2* K = spec + (int64_t)c * (M + 1);
+  float2* out = coef + (int64_t)c * 3 * H;
+  const double inv_m = 1.0 / (double)M;
+  if (kk == 0) {
+    out[0] = make_float2((float)((double)K[0].x * inv_m), (float)((double)K[M].x * inv_m));
+    out[H] = make_float2(0.f, 0.f);
+    out[2 * H] = make_float2(0.f, 0.f);
+    return;
+  }
+  const float2 p = K[kk], q = K[M - kk], w = twq[kk * qstep];
+  const double px = p.x, py = p.y, qx = q.x, qy = -(double)q.y;  // Qc = conj(K[M-k])
+  const double sx = 0.5 * (px + qx), sy = 0.5 * (py + qy), dx = 0.5 * (px - qx), dy = 0.5 * (py - qy);
+  const double cw = w.x, sw = w.y;
+  out[kk] = make_float2((float)((sx + sw * dx) * inv_m), (float)((sy + sw * dy) * inv_m));
+  out[H + kk] = make_float2((float)((sx - sw * dx) * inv_m), (float)((sy - sw * dy) * inv_m));
+  out[2 * H + kk] = make_float2((float)(-cw * dy * inv_m), (float)(cw * dx * inv_m));  // i c (dx + i dy)
+}
+
+// Complex multiply-accumulate on packed fp32 with every swizzle and sign as an operand modifier of v_pk_fma_f32 (op_sel picks the
+// half of a source per result lane, neg_lo / neg_hi negate a source per lane): two instructions per complex product, no moves.
+// (Written as vector code hipcc built the rotated operand (-x.y, x.x) with a v_xor + v_mov per product: 7 of 20 instructions
+// of a pair.)   r = acc + a x:   lo = a.x x.x - a.y x.y + acc.x,   hi = a.x x.y + a.y x.x + acc.y
+#define DC_PK_FMA(dst, s0, s1, s2, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(dst) : "v"(s0), "v"(s1), "v"(s2))
+__device__ __forceinline__ v2f pm_mul(v2f a, v2f x) {  // a x
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(x));  // a.xx * x
+  DC_PK_FMA(r, a, x, r, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]");     // + a.yy * (-x.y, x.x)
+  return r;
+}
+__device__ __forceinline__ v2f pm_nmul(v2f a, v2f x) {  // -(a x)
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(x));
+  DC_PK_FMA(r, a, x, r, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]");
+  return r;
+}
+__device__ __forceinline__ v2f pm_fma_conj(v2f cm, v2f x, v2f acc) {  // acc + conj(cm) x
+  v2f r;
+  DC_PK_FMA(r, cm, x, acc, "op_sel_hi:[0,1,1]");                                  // + cm.xx * x
+  DC_PK_FMA(r, cm, x, r, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]");      // - cm.yy * (-x.y, x.x)
+  return r;
+}
+__device__ __forceinline__ v2f pm_fma_conj_out_conj(v2f cm, v2f x, v2f acc) {  // conj(acc + conj(cm) x): the last step negates its hi lane
+  v2f r;
+  DC_PK_FMA(r, cm, x, acc, "op_sel_hi:[0,1,1]");
+  DC_PK_FMA(r, cm, x, r, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]");      // hi: -(-cm.y x.x + r.y) = cm.y x.x - r.y
+  return r;
+}
+
+template <int LOGN, int Q, bool TAB, int SP, bool PM>
 __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(HyenaArgs a, const int32_t* __restrict__ reads,
                                                                           const float2* __restrict__ tw,
                                                                           const float2* __restrict__ twq, int qstep,
-                                                                          const float2* __restrict__ spec) {
+                                                                          const float2* __restrict__ spec) {  // PM: the pair maps
   using G = SplitGeo<LOGN, Q>;
   constexpr int N2 = G::N2, M = G::M, T = G::T, TG = G::TG, NZ = G::NZ, ROW = G::ROW;
   // "one n2 per thread" iterations.  Q == 1 (one row, no outer step): input and wanted output fill the first half of the row
@@ -816,7 +884,6 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
   fft_lds<LOGN>(s + grp * ROW, tw, tid - grp * TG);
 
   // ---- spectrum product and repacking for the inverse transform (stored conjugated: IFFT = conj . FFT . conj) ----
-  const float2* K = spec + (int64_t)c * (M + 1);
   // Bin kk_j = tid + j T lives in row kk mod Q = tid mod Q (T is a multiple of Q) at index kk / Q = tid / Q + j T / Q, and
   // T / Q = N2 / 16 is a multiple of 16: its padded slot is that of tid plus j (T / Q) 17 / 16, its partner's (M - kk_j) that of
   // M - tid minus the same -- two addresses per thread, constant offsets
@@ -824,6 +891,43 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
   static_assert(T % Q == 0 && (T / Q) % 16 == 0, "bin slots by constant strides");
   float2* const pk0 = s + split_at<LOGN, Q>(tid);
   float2* const pmk0 = s + split_at<LOGN, Q>(M - tid);  // (thread 0: bin M, one slot behind row 0 -- never dereferenced, see product)
+  if constexpr (PM) {
+    // One 2 x 2 complex map per pair (hyena_fft_pairmap_kernel): u = A a + B b -> conj(u) to bin k, v = -B a + A' b to bin M - k,
+    // a = C[k], b = conj(C[M-k]).  All twenty-four coefficient loads of the thread in flight at once.
+    constexpr int H = M / 2 + 1;
+    const float2* CA = spec + (int64_t)c * 3 * H;
+    float2 ca[8], cp[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = tid + j * T;
+      ca[j] = CA[kk];
+      cp[j] = CA[H + kk];
+      cb[j] = CA[2 * H + kk];
+    }
+    const float2 am = CA[M / 2];  // the self-paired middle bin: B = 0, u = A a
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float2* const pk = pk0 + j * KSTEP;
+      float2* const pmk = pmk0 - j * KSTEP;
+      const v2f a = V(*pk);
+      if (j == 0 && tid == 0) {  // bin 0: Y[0] = (Re + Im) K[0], Y[M] = (Re - Im) K[M], both real; C'[0] = (Y0 + YM) / 2 + i (Y0 - YM) / 2
+        const float y0 = (a.x + a.y) * ca[0].x, ym = (a.x - a.y) * ca[0].y;
+        *pk = make_float2(0.5f * (y0 + ym), -0.5f * (y0 - ym));
+      } else {
+        const v2f cm = V(*pmk);  // b = conj(cm)
+        const v2f A = V(ca[j]), A2 = V(cp[j]), B = V(cb[j]);
+        *pk = F(pm_fma_conj_out_conj(cm, B, pm_mul(a, A)));   // conj(u), u = A a + B b
+        *pmk = F(pm_fma_conj(cm, A2, pm_nmul(a, B)));         // v = -B a + A' b
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid == 0) {
+      float2* const pm = s + split_at<LOGN, Q>(M / 2);
+      const v2f u = pm_mul(V(*pm), V(am));
+      *pm = make_float2(u.x, -u.y);
+    }
+  } else {
+  const float2* K = spec + (int64_t)c * (M + 1);
   auto product = [&](int kk, float2* pk, float2* pmk, float2 kf_, float2 kb_, float2 wk_) {  // kf = K[kk], kb = K[M - kk], wk = W_2M^kk
     const v2f ck = V(*pk);
     const v2f kf = V(kf_), kb = V(kb_), wk = V(wk_);
@@ -870,6 +974,7 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
     }
     if (tid == 0) product(M / 2, s + split_at<LOGN, Q>(M / 2), s + split_at<LOGN, Q>(M / 2), km, km, wm);  // the self-paired middle bin
   }
+  }
   __syncthreads();
 
   fft_lds<LOGN>(s + grp * ROW, tw, tid - grp * TG);
@@ -892,7 +997,7 @@ __global__ __launch_bounds__(Q * (1 << LOGN) / 16, 4) void hyena_fftq_kernel(Hye
   }
 
   // ---- outer inverse step for the wanted half, output gate: conv[2n] = Re r[n] / M, conv[2n+1] = -Im r[n] / M ----
-  const float inv_m = 1.0f / (float)M;
+  const float inv_m = PM ? 1.0f : 1.0f / (float)M;  // (PM: folded into the pair maps)
   float* y = a.y + (int64_t)c * a.Tp + g.toff;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -1176,12 +1281,24 @@ int launch_filter_q(hipStream_t st, const float* kf, int64_t kf_stride, int kf_t
   return DC_OK;
 }
 
+// the pair maps stand behind the spectra in a class's buffer (hyena_fft_spec_floats); DC_FFT_PAIRMAP=0 keeps round 5's product (A/B)
+bool fft_pairmap() {  // (read per launch: a test flips it between two forwards of one process)
+  const char* e = getenv("DC_FFT_PAIRMAP");
+  return !(e && atoi(e) == 0);
+}
+
 template <int LOGN, int Q, bool TAB, int SP>
 int launch_fftq_t2(hipStream_t st, const HyenaArgs& a, const int32_t* reads, int n_reads, const float2* tw, const float2* spec) {
   using G = SplitGeo<LOGN, Q>;
-  DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fftq_kernel<LOGN, Q, TAB, SP>), G::smem);
-  hipLaunchKernelGGL((hyena_fftq_kernel<LOGN, Q, TAB, SP>), dim3(n_reads, a.D), dim3(G::T), G::smem, st, a, reads, tw,
-                     tw + split_tw_off<Q>(), split_tw_step<LOGN, Q>(), spec);
+  if (fft_pairmap()) {
+    DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fftq_kernel<LOGN, Q, TAB, SP, true>), G::smem);
+    hipLaunchKernelGGL((hyena_fftq_kernel<LOGN, Q, TAB, SP, true>), dim3(n_reads, a.D), dim3(G::T), G::smem, st, a, reads, tw,
+                       tw + split_tw_off<Q>(), split_tw_step<LOGN, Q>(), spec + (int64_t)a.D * (G::M + 1));
+  } else {
+    DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&hyena_fftq_kernel<LOGN, Q, TAB, SP, false>), G::smem);
+    hipLaunchKernelGGL((hyena_fftq_kernel<LOGN, Q, TAB, SP, false>), dim3(n_reads, a.D), dim3(G::T), G::smem, st, a, reads, tw,
+                       tw + split_tw_off<Q>(), split_tw_step<LOGN, Q>(), spec);
+  }
   DC_LAUNCH_CHECK();
   return DC_OK;
 }
@@ -1211,9 +1328,37 @@ int launch_fft_twiddles(hipStream_t st, float* tw) {
 }
 int fft_twiddle_count() { return FFT_TW_TOTAL; }
 
+// classes the staged / split kernel serves (hyena_fftq_kernel): their buffers carry the pair maps behind the spectra
+static bool fftq_class(const FftClassInfo& ci) { return ci.q >= 2 || (ci.q == 1 && ci.points == 4096); }
+
+int64_t hyena_fft_spec_floats(int cls, int D) {
+  const FftClassInfo& ci = kFftClass[cls];
+  int64_t n = (int64_t)D * ((int64_t)ci.points + 1) * 2;
+  if (fftq_class(ci)) n += (int64_t)D * 3 * ((int64_t)ci.points / 2 + 1) * 2;
+  return n;
+}
+
+static int launch_hyena_fft_filter_spectra(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
+                                           const float* tw, float* spec);
+
 int launch_hyena_fft_filter(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
                             const float* tw, float* spec) {
   DC_REQUIRE(cls >= 0 && cls < kFftClasses, "FFT long convolution: no such size class");
+  int rc = launch_hyena_fft_filter_spectra(st, cls, kf, kf_stride, kf_taps, D, tw, spec);
+  const FftClassInfo& ci = kFftClass[cls];
+  if (rc || !fftq_class(ci)) return rc;
+  const int M = ci.points;
+  const float2* t2 = reinterpret_cast<const float2*>(tw);
+  float2* s2 = reinterpret_cast<float2*>(spec);
+  const bool q3 = ci.q == 3;  // W_2M^k: the 24 576-th roots for 3 x 4096 points, the 2^16 table otherwise
+  hipLaunchKernelGGL(hyena_fft_pairmap_kernel, dim3((M / 2 + 1 + 255) / 256, D), dim3(256), 0, st, (const float2*)s2,
+                     t2 + (q3 ? FFT_TW3_OFF : 0), (q3 ? FFT_TW3_N : FFT_TW_N) / (2 * M), M, s2 + (int64_t)D * (M + 1));
+  DC_LAUNCH_CHECK();
+  return DC_OK;
+}
+
+static int launch_hyena_fft_filter_spectra(hipStream_t st, int cls, const float* kf, int64_t kf_stride, int kf_taps, int D,
+                                           const float* tw, float* spec) {
   const FftClassInfo& ci = kFftClass[cls];
   const float2* t2 = reinterpret_cast<const float2*>(tw);
   float2* s2 = reinterpret_cast<float2*>(spec);

@@ -331,7 +331,10 @@ class PredictPipeline:
                     hb = slot.pin.get("out_" + k, t.numel() * t.element_size())
                     hb.view(t.dtype).view(t.shape).copy_(t, non_blocking=True) if t.numel() else None
                     host[k] = hb.numpy().view(_NP[t.dtype]).reshape(tuple(t.shape))
-                copied = torch.cuda.Event()
+                # (blocking: the host thread SLEEPS in collect() until the copy has landed.  The default event spins in
+                #  hipEventSynchronize: one core per rank at 100 % for the whole run -- measured at two ranks on a shared card,
+                #  profiles/r06_bench_2rank_shared_gpu.json: 2.0 cores per rank, whatever its throughput)
+                copied = torch.cuda.Event(blocking=True)
                 copied.record(copy_stream)
             return {"slot": slot, "res": res, "d_in": (d_seq, d_qual, d_offs), "host": host, "copied": copied}
 
@@ -562,7 +565,7 @@ class PtWriter:
                 self._stream.wait_stream(torch.cuda.current_stream(dev))
             ops.pt_pack(logits, labels, ids_t, quals, table, self._d_out)
             pinned[:total].copy_(self._d_out[:total], non_blocking=True)
-            copied = torch.cuda.Event()
+            copied = torch.cuda.Event(blocking=True)  # (the writer's waits sleep, as the pipeline's do)
             copied.record(self._stream)
         t2 = time.perf_counter()
         self.timers["pack_enqueue"] += t2 - t1

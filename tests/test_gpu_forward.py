@@ -784,6 +784,54 @@ def test_split_fft_classes_match_the_power_of_two_transforms(env):
         model.set_profiling(False)
 
 
+def test_fft_pair_maps_match_the_unpack_multiply_repack_form(env):
+    """Round 6: between its two transforms the split / staged FFT kernel applies ONE precomputed 2 x 2 complex map per conjugate
+    pair (hyena_fft_pairmap_kernel: unpack, filter product, repack and the 1 / M of the inverse folded into A, A', B; 8 packed
+    FMAs per pair) instead of round 5's unpack -> multiply -> repack (DC_FFT_PAIRMAP=0 keeps that form).  Same mathematics:
+    every size class the kernel serves (4 096 one row, 2 / 3 / 4 x 4 096), dense rows and a left-padded batch in both
+    shared-prefix forms, agree with the round-5 form to fp32 rounding and stay inside the parity tolerance of the oracle."""
+    torch, ops, sd, model = env
+    from oracle import forward_ref as fr
+
+    rng = np.random.default_rng(606)
+    lens = [2600, 4095, 4096, 4097, 7000, 8192, 8193, 12288, 12289, 16383, 16384]
+    stride = max(lens)
+    ids = np.full((len(lens), stride), 4, np.uint8)
+    q = np.zeros((len(lens), stride), np.float32)
+    for r, n in enumerate(lens):
+        i_r, q_r = _inputs(rng, 1, n)
+        ids[r, :n], q[r, :n] = i_r[0], q_r[0]
+    first, ntok = np.zeros(len(lens), np.int32), np.array(lens, np.int32)
+    d_ids, d_q = ops.to_device(ids), ops.to_device(q)
+    pids, pq, pfirst, pntok, pnpad = _padded_launch(rng, [[9000, 3000, 5000, 700], [12000, 2700]])
+    d_pids, d_pq = ops.to_device(pids), ops.to_device(pq)
+    before = os.environ.get("DC_FFT_PAIRMAP")
+    outs = {}
+    try:
+        for pm in ("0", "1"):
+            os.environ["DC_FFT_PAIRMAP"] = pm
+            o = {"ragged": model.forward_ragged(d_ids, d_q, first, ntok).cpu().numpy()}
+            for form in ("exact", "linear"):
+                model.set_prefix_mode(form)
+                o[form] = model.forward_shared_prefix(d_pids, d_pq, pfirst, pntok, pnpad).cpu().numpy()
+            outs[pm] = o
+    finally:
+        model.set_prefix_mode("exact")
+        if before is None:
+            os.environ.pop("DC_FFT_PAIRMAP", None)
+        else:
+            os.environ["DC_FFT_PAIRMAP"] = before
+    worst = {}
+    for k in ("ragged", "exact", "linear"):
+        assert np.isfinite(outs["1"][k]).all()
+        worst[k] = float(np.abs(outs["1"][k] - outs["0"][k]).max())
+    print(f"pair maps vs unpack-multiply-repack ({model.gemm_mode}): max |dlogit| {worst}")
+    assert max(worst.values()) < 1e-4, worst
+    for r in (1, 4, 7, 10):  # one read per size class against the oracle
+        n = lens[r]
+        _check(outs["1"]["ragged"][r, :n], fr.forward(sd, ids[r: r + 1, :n].astype(np.int64), q[r: r + 1, :n]).numpy()[0])
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # dc_forward_shared_prefix: the reference's left-padded batches with the [PAD] runs of all rows computed once per launch
 # ----------------------------------------------------------------------------------------------------------------

@@ -65,6 +65,31 @@ def _gather(obj, world: int):
     return out
 
 
+def _thread_cpu() -> dict:
+    """CPU seconds of every thread of this process so far: {tid: (name, seconds)} from /proc (who burns the host budget?)."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as fh:
+                    st = fh.read()
+                name = st[st.index("(") + 1: st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)  # utime + stime
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
+def _top_threads(before: dict, after: dict, k: int = 5) -> list:
+    d = [(after[t][0], round(after[t][1] - before.get(t, ("", 0.0))[1], 2)) for t in after]
+    d.sort(key=lambda x: -x[1])
+    return [f"{n}: {c}" for n, c in d[:k] if c > 0.0]
+
+
 def _per_k(cpu_s: float, reads: int) -> float:
     return round(1000.0 * cpu_s / max(reads, 1), 4)
 
@@ -150,6 +175,7 @@ def c3_sharded_leg(pipe, sd, rank: int, world: int, reads_per_rank: int, read_le
             if bad:
                 return {"error": f"{phase.__name__}: {bad}"} if rank == 0 else None
         gen_s = time.perf_counter() - t_gen
+        th0 = _thread_cpu()
         c0, t0 = time.process_time(), time.perf_counter()
         marks = [(0, t0)]
         state = {"n": 0, "n_iv": 0, "first": None}
@@ -187,6 +213,7 @@ def c3_sharded_leg(pipe, sd, rank: int, world: int, reads_per_rank: int, read_le
         tenth = max(n // 10, 1)
         mine = {"rank": rank, "reads": n, "seconds": round(own_s, 3), "reads_per_s": round(n / max(own_s, 1e-9), 1),
                 "cpu_s": round(cpu_s, 3), "cpu_s_per_1000_reads": _per_k(cpu_s, n), "intervals": state["n_iv"], "cpuset": cpuset,
+                "cpu_s_top_threads": _top_threads(th0, _thread_cpu()),
                 "first_tenth_reads_per_s": rate_between(0, tenth), "last_tenth_reads_per_s": rate_between(n - tenth, n)}
         ranks = _gather(mine, world)
         walls = _gather(wall, world)
@@ -317,6 +344,7 @@ def c5_legs(rank: int, world: int, reads_per_rank: int, threads: int = 4, cpuset
                  "the same reads as BGZF: no feeder, every rank inflates its own contiguous block range; parts concatenated rank by rank")):
             try:
                 _barrier()
+                th0 = _thread_cpu()
                 c0, t1 = time.process_time(), time.perf_counter()
                 rep = predict_chop_as_external_rank(path, pipe, rank, world, threads=threads, chop_output=os.path.join(tmp, name), quiet=True)
                 torch.cuda.synchronize()
@@ -327,6 +355,7 @@ def c5_legs(rank: int, world: int, reads_per_rank: int, threads: int = 4, cpuset
                         "reads_per_s": round(rep["reads"] / max(rep.get("stream_s") or wall, 1e-9), 1),
                         "cpu_s": {"worker": round(cpu - feeder_cpu, 3), "bgzf_deflate": round(float(chop_mod.LAST_WRITER_STATS.get("deflate_cpu_s", 0.0)), 3),
                                   "pipe_read": rep.get("pipe_read_cpu_s", 0.0), "feeder": feeder_cpu},
+                        "cpu_s_top_threads": _top_threads(th0, _thread_cpu()),
                         "cpuset": cpuset, "feeder_cpuset": rep.get("feeder_cpuset"), "input": rep["input"], "merge_s": rep.get("merge_s"),
                         "final": rep.get("final")}
                 ranks = _gather(mine, world)
@@ -334,7 +363,8 @@ def c5_legs(rank: int, world: int, reads_per_rank: int, threads: int = 4, cpuset
                 if rank != 0:
                     continue
                 wall = max(walls)
-                cs = lambda k: sum(r["cpu_s"][k] for r in ranks)  # noqa: E731
+                tot = {k: sum(r["cpu_s"][k] for r in ranks) for k in ("worker", "bgzf_deflate", "pipe_read", "feeder")}
+                cs = tot.__getitem__
                 for r in ranks:
                     r["cpu_s_per_1000_reads"] = {k: _per_k(v, r["reads"]) for k, v in r.pop("cpu_s").items() if k != "feeder"}
                 final = ranks[0].pop("final")
