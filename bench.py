@@ -256,6 +256,7 @@ def main():
 
     # N > 1: a disjoint slice of its GPU's NUMA node's CPUs per rank -- before torch is imported and the GPU is touched, so
     # that helper threads inherit it and pinned staging is allocated after binding (deepchopper_amd/placement.py)
+    JOB_USABLE_CPUS = placement.usable_cpu_count()  # before this rank binds itself to its slice
     placed = placement.apply_for_this_rank()
     import torch
 
@@ -375,6 +376,7 @@ def main():
         from tools import bench_multi
 
         my_cpus = placed and placed["cpuset"]
+        bench_multi.JOB_CPU_BUDGET = (placed and placed.get("cpu_budget")) or JOB_USABLE_CPUS
         multi = {}
         wanted = [x for x in args.multi_legs.split(",") if x]
         if "c3" in wanted:

@@ -63,6 +63,27 @@ class _Slot:
         self.n = 0
 
 
+def wait_event(ev) -> None:
+    """Wait for a CUDA/HIP event WITHOUT burning a core.  `event.synchronize()` spins on this stack -- with
+    `Event(blocking=True)` as well: measured 100 % of one core in the wait for the whole run, plus a runtime thread beside it
+    (tools/spin_probe.py, profiles/r06_spin_probe.jsonl) -- which at one rank per GPU is two cores per rank spent on waiting,
+    more than the rank's parse + staging + BGZF work together.  Polling `query()` between short sleeps costs a few hundred
+    wake-ups per batch of tens of milliseconds and at most half a millisecond of latency.  DC_EVENT_WAIT=sync keeps
+    synchronize() (A/B)."""
+    if _EVENT_WAIT_SYNC:
+        ev.synchronize()
+        return
+    pause = 50e-6
+    while not ev.query():
+        time.sleep(pause)
+        if pause < 500e-6:
+            pause *= 2
+
+
+_EVENT_WAIT_SYNC = os.environ.get("DC_EVENT_WAIT", "poll") == "sync"
+_COPY_STREAM = os.environ.get("DC_COPY_STREAM", "0") == "1"
+
+
 class PredictPipeline:
     """tokenise -> forward -> smooth on device-resident batches."""
 
@@ -71,6 +92,9 @@ class PredictPipeline:
         self.max_length = max_length
         self.smooth = smooth or SmoothParams()
         self._copy_stream = None
+        # main-thread seconds of predict_stream: enqueueing a batch (wall / CPU) and waiting for a batch's results (wall / CPU --
+        # a wait that SLEEPS costs no CPU; tools/spin_probe.py)
+        self.stream_timers = {"launch_s": 0.0, "launch_cpu_s": 0.0, "wait_s": 0.0, "wait_cpu_s": 0.0}
         # reference_padding: rows share their [PAD] prefix (dc_forward_shared_prefix) instead of running it once per row;
         # DC_SHARED_PREFIX=0 keeps the padded launches (A/B, parity tests)
         self.shared_prefix = os.environ.get("DC_SHARED_PREFIX", "1") != "0"
@@ -316,31 +340,41 @@ class PredictPipeline:
             finally:
                 if guard:
                     net.set_overflow_target(None)
-            done = torch.cuda.Event()
-            done.record(compute)
-            # results -> pinned host memory on the copy stream
+            # results -> pinned host memory, on the COMPUTE stream behind the batch's own kernels.  (Rounds 1-5 used a second
+            # stream behind an event of the compute stream: on this stack a cross-stream event wait is resolved by a runtime
+            # thread that busy-waits on the host for as long as the awaited work runs -- one core per rank at ~95 % for the
+            # whole run (tools/spin_probe_torch.py: same-stream copy 0.01 s of runtime-thread CPU, cross-stream 0.26 s per
+            # 0.8 s; the pipeline 2.6 s of 2.8 s).  The copies are a few MB per launch of tens of milliseconds: in line they
+            # cost < 0.5 % of the step, and batch k + 1 is enqueued before the host waits for batch k either way.
+            # DC_COPY_STREAM=1 keeps the second stream (A/B).)
             sm = res["smooth"]
             outs = {"status": res["tok"]["status"], "guard": counter, "intervals": sm["intervals"],
                     "n_intervals": sm["n_intervals"], "keep": sm["keep"], "n_keep": sm["n_keep"]}
             if want_labels:
                 outs["pred"], outs["smooth"] = sm["pred"], sm["smooth"]
             host = {}
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(done)
+            side = copy_stream if _COPY_STREAM else compute
+            if _COPY_STREAM:
+                done = torch.cuda.Event()
+                done.record(compute)
+            with torch.cuda.stream(side):
+                if _COPY_STREAM:
+                    copy_stream.wait_event(done)
                 for k, t in outs.items():
                     hb = slot.pin.get("out_" + k, t.numel() * t.element_size())
                     hb.view(t.dtype).view(t.shape).copy_(t, non_blocking=True) if t.numel() else None
                     host[k] = hb.numpy().view(_NP[t.dtype]).reshape(tuple(t.shape))
-                # (blocking: the host thread SLEEPS in collect() until the copy has landed.  The default event spins in
-                #  hipEventSynchronize: one core per rank at 100 % for the whole run -- measured at two ranks on a shared card,
-                #  profiles/r06_bench_2rank_shared_gpu.json: 2.0 cores per rank, whatever its throughput)
-                copied = torch.cuda.Event(blocking=True)
-                copied.record(copy_stream)
+                copied = torch.cuda.Event()
+                copied.record(side)
             return {"slot": slot, "res": res, "d_in": (d_seq, d_qual, d_offs), "host": host, "copied": copied}
 
         def collect(b):
             slot, res, host = b["slot"], b["res"], b["host"]
-            b["copied"].synchronize()
+            t_w = time.perf_counter()
+            c_w = time.thread_time()
+            wait_event(b["copied"])
+            self.stream_timers["wait_s"] += time.perf_counter() - t_w
+            self.stream_timers["wait_cpu_s"] += time.thread_time() - c_w
             if int(host["guard"][0]) > 0:  # this batch (and only this one) left the fp16 range: redo it in bf16x6
                 res = self._rerun_bf16x6(*b["d_in"], slot.lens, reference_padding=reference_padding,
                                          want_labels=want_labels, ids_i64=ids_i64,
@@ -379,7 +413,10 @@ class PredictPipeline:
                 item = q.get()
                 if isinstance(item, BaseException):
                     raise item
+                t_l, c_l = time.perf_counter(), time.thread_time()
                 launched = launch(item) if item is not None else None
+                self.stream_timers["launch_s"] += time.perf_counter() - t_l
+                self.stream_timers["launch_cpu_s"] += time.thread_time() - c_l
                 if serialize and launched is not None:
                     launched["copied"].synchronize()
                 if pending is not None:
@@ -595,7 +632,7 @@ class PtWriter:
             oldest = False
             copied, args, _dev_keep, pinned = self._staged.pop(0)
             t0 = time.perf_counter()
-            copied.synchronize()
+            wait_event(copied)
             self.timers["wait_copy"] += time.perf_counter() - t0
             d, rank, first_index, row0, subs, n_cols, pay_off, total, n, names, offs, truncated = args
             ticket = C.c_int64(0)

@@ -85,7 +85,10 @@ def _thread_cpu() -> dict:
 
 
 def _top_threads(before: dict, after: dict, k: int = 5) -> list:
-    d = [(after[t][0], round(after[t][1] - before.get(t, ("", 0.0))[1], 2)) for t in after]
+    import threading
+
+    py = {t.native_id: t.name for t in threading.enumerate()}  # Python threads by name; the rest are the runtime's / the library's
+    d = [((f"py:{py[t]}" if t in py else f"native:{after[t][0]}"), round(after[t][1] - before.get(t, ("", 0.0))[1], 2)) for t in after]
     d.sort(key=lambda x: -x[1])
     return [f"{n}: {c}" for n, c in d[:k] if c > 0.0]
 
@@ -94,12 +97,16 @@ def _per_k(cpu_s: float, reads: int) -> float:
     return round(1000.0 * cpu_s / max(reads, 1), 4)
 
 
+JOB_CPU_BUDGET = None  # CPUs' worth of time the WHOLE job may use; set by bench.py from the placement plan (a rank that has been
+                       # bound to its slice sees only the slice in its own affinity mask)
+
+
 def host_verdict(cpu_s_total: float, wall_s: float, reads: int, world: int, gpu_bound_rate: float) -> dict:
     """Was the flow at the host's limit, and would it be at N GPU-bound GPUs?  `cores_used` = CPU seconds consumed per second of
     wall (all processes of the flow); `budget` = CPUs' worth of time the job may use."""
     from deepchopper_amd import placement
 
-    budget = placement.usable_cpu_count()
+    budget = JOB_CPU_BUDGET or placement.usable_cpu_count()
     used = cpu_s_total / max(wall_s, 1e-9)
     need = cpu_s_total / max(reads, 1) * gpu_bound_rate * world  # cores needed to feed `world` GPUs that are each GPU-bound
     return {"cpu_s_total": round(cpu_s_total, 2), "cores_used": round(used, 2), "cpu_budget_cores": budget,
