@@ -28,6 +28,7 @@ struct LayerDev {
   unsigned short *Wq_in = nullptr, *Wq_out = nullptr, *Wq_fc1 = nullptr, *Wq_fc2 = nullptr;  // fp16 planes (scaled)
   unsigned short* Wq_fc2p = nullptr;  // fc2 planes with the k order of the fused MLP kernel (mlp_fused_perm16)
   unsigned short* Wq_inp = nullptr;   // in_proj planes in that k order (B operand = the previous block's MLP output)
+  unsigned short *Wp_fc2p = nullptr, *Wp_inp = nullptr;  // the same two in the bf16x6 planes (strict mode's fused MLP kernel)
   float is_in = 1.f, is_out = 1.f, is_fc1 = 1.f, is_fc2 = 1.f;                              // 1 / weight scale
   // implicit filter parameters (device copies, checkpoint layout)
   float *pos_z = nullptr, *pos_t = nullptr, *fw0 = nullptr, *fb0 = nullptr, *fw1 = nullptr, *fb1 = nullptr,
@@ -60,6 +61,7 @@ struct dc_model {
   unsigned short *Wp_l1 = nullptr, *Wp_l2 = nullptr;
   unsigned short *Wq_l1 = nullptr, *Wq_l2 = nullptr;
   unsigned short* Wq_l1p = nullptr;  // head linear1 planes in the fused MLP kernel's k order
+  unsigned short* Wp_l1p = nullptr;  // ... as bf16x6 planes
   int mlp_chain = 1;                 // fused MLP kernel also runs the GEMM that consumes LayerNorm(its output)
   float is_l1 = 1.f, is_l2 = 1.f;
   int* d_overflow = nullptr;  // fp16x3 range guard (device counter)
@@ -982,8 +984,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       }
     }
     const bool no_mlp_fuse = getenv("DC_NO_MLP_FUSE") != nullptr;  // A/B switch
-    const bool fused_mlp = m->gemm_mode == 2 && sums && !no_mlp_fuse && m->mlp_fusion && L.Wq_fc2p && D == 256 &&
-                           DI % 128 == 0 && DI <= 1024;
+    // fp16x3 (mode 2) and, since round 6, the strict bf16x6 arithmetic (mode 1: mlp_fused6_kernel; DC_NO_MLP_FUSE6 keeps its
+    // three plain GEMM launches, A/B)
+    const bool strict = m->gemm_mode == 1;
+    const bool fused_mlp = (m->gemm_mode == 2 || (strict && getenv("DC_NO_MLP_FUSE6") == nullptr)) && sums && !no_mlp_fuse &&
+                           m->mlp_fusion && (strict ? L.Wp_fc2p : L.Wq_fc2p) && D == 256 && DI % 128 == 0 && DI <= 1024;
     if (sums && (rc = zero_stats())) return rc;
     if ((rc = run_gemm(m, st, "gemm_outproj", WRef{L.Wt_out, L.Wp_out, L.Wq_out, L.is_out}, y, x, L.b_out, x, nullptr, false,
                        sums ? EPI_BIAS_RES_STATS : EPI_BIAS_RES, D, D)))
@@ -996,11 +1001,11 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       // fc1 -> GELU -> fc2 -> +residual -> LayerNorm statistics in one kernel; the d_inner-wide
       // activation stays in registers (fp16x3 only)
       GemmArgs g{};
-      g.Wp = L.Wq_fc1;
-      g.Wp2 = L.Wq_fc2p;
-      g.split_mode = 1;
-      g.w_inv_scale = L.is_fc1;
-      g.w_inv_scale2 = L.is_fc2;
+      g.Wp = strict ? L.Wp_fc1 : L.Wq_fc1;
+      g.Wp2 = strict ? L.Wp_fc2p : L.Wq_fc2p;
+      g.split_mode = strict ? 0 : 1;
+      g.w_inv_scale = strict ? 1.0f : L.is_fc1;  // (bf16 planes hold the weights themselves: no power-of-two scale to undo)
+      g.w_inv_scale2 = strict ? 1.0f : L.is_fc2;
       g.bias = L.b_fc1;
       g.bias2 = L.b_fc2;
       g.overflow = m->ovf_target ? m->ovf_target : m->d_overflow;
@@ -1021,19 +1026,19 @@ int forward_core(dc_model* m, hipStream_t st, const void* d_ids, int ids_i64, co
       // taken from the accumulator registers: the next block's in_proj, or the head's linear1 after the last block
       u_ready = false;
       const bool chain = !no_mlp_chain && m->mlp_chain;
-      if (chain && li + 1 < c.n_layer && m->layers[li + 1].Wq_inp && (3 * D) % 128 == 0) {
+      if (chain && li + 1 < c.n_layer && (strict ? m->layers[li + 1].Wp_inp : m->layers[li + 1].Wq_inp) && (3 * D) % 128 == 0) {
         LayerDev& Ln = m->layers[li + 1];
-        g.Wp3 = Ln.Wq_inp;
+        g.Wp3 = strict ? Ln.Wp_inp : Ln.Wq_inp;
         g.bias3 = Ln.b_in;
-        g.w_inv_scale3 = Ln.is_in;
+        g.w_inv_scale3 = strict ? 1.0f : Ln.is_in;
         g.N3 = 3 * D;
         g.epi3 = EPI_BIAS;
         g.C3 = u;
         u_ready = true;
-      } else if (chain && li + 1 == c.n_layer && m->Wq_l1p && H % 128 == 0) {
-        g.Wp3 = m->Wq_l1p;
+      } else if (chain && li + 1 == c.n_layer && (strict ? m->Wp_l1p : m->Wq_l1p) && H % 128 == 0) {
+        g.Wp3 = strict ? m->Wp_l1p : m->Wq_l1p;
         g.bias3 = m->b_l1;
-        g.w_inv_scale3 = m->is_l1;
+        g.w_inv_scale3 = strict ? 1.0f : m->is_l1;
         g.N3 = H;
         g.epi3 = EPI_BIAS_RELU_Q;
         g.C3 = hm;
@@ -1129,6 +1134,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
         memcpy(&Wtp[(size_t)k * 3 * D], &Wt[(size_t)(mlp_fused_perm(k)) * 3 * D], (size_t)3 * D * sizeof(float));
       float is_p = 0.f;
       UP(upload_planes_f16(m, Wtp, D, 3 * D, &L.Wq_inp, &is_p));
+      UP(upload_planes(m, Wtp, D, 3 * D, &L.Wp_inp));
     }
     if (li == 0) {
       // u0[v][n] = b'[n] + sum_k Wt[k][n] * (emb[v][k] - mean_v) * rstd_v   (gamma / beta already folded), fp64
@@ -1179,6 +1185,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
         memcpy(&Wtp[(size_t)k * D], &Wt[(size_t)(mlp_fused_perm(k)) * D], (size_t)D * sizeof(float));
       float is_p = 0.f;
       UP(upload_planes_f16(m, Wtp, DI, D, &L.Wq_fc2p, &is_p));  // same values, same power-of-two scale as Wq_fc2
+      UP(upload_planes(m, Wtp, DI, D, &L.Wp_fc2p));
     }
     UP(upload(m, bo, &L.b_fc2));
     UP(upload_raw(m, lw.pos_z, (size_t)cfg->max_seq_len * emb, &L.pos_z));
@@ -1206,6 +1213,7 @@ extern "C" int dc_model_create(const dc_model_config* cfg, const dc_model_weight
       memcpy(&Wtp[(size_t)k * H], &Wt[(size_t)(mlp_fused_perm(k)) * H], (size_t)H * sizeof(float));
     float is_p = 0.f;
     UP(upload_planes_f16(m, Wtp, D, H, &m->Wq_l1p, &is_p));
+    UP(upload_planes(m, Wtp, D, H, &m->Wp_l1p));
   }
   UP(upload(m, bo, &m->b_l1));
   fold_transpose(w->head_w2, w->head_b2, nullptr, nullptr, H, H, Wt, bo);

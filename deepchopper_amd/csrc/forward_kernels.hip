@@ -1284,28 +1284,415 @@ __global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused_kernel(GemmArgs g) {
   }
 }
 
+// =====================================================================================
+// Fused MLP, strict arithmetic (bf16x6; round 6): the same kernel shape for the error-free three-plane split -- the mode the
+// fp16 range guard falls back to and the one "no narrower than fp32" figure of the bench line.  Rounds 1-5 ran it as three
+// plain GEMM launches (fc1 | fc2 | the next in_proj) with the d_inner-wide activation going through HBM.
+// What changes against the fp16x3 kernel above:
+//   * three operand planes: a k16 step is SIX MFMAs per 32 x 32 tile instead of three, so the steps are 16 deep instead of 32
+//     (the same 24 MFMAs per wave between two barriers) and a ring slot is 28 KiB: fc1 tile 3 x 2 octets x 128 hidden (12 KiB)
+//     + X tile 16 x 256 tokens fp32 (16 KiB); fc2 tile 3 x 2 x 256 outputs = 24 KiB; W3 tile (32 deep) 3 x 4 x 128 = 24 KiB.
+//     The fc1 step's 28 DMA pieces do not divide by 8 waves: waves 0-3 issue four, waves 4-7 three, and wait accordingly.
+//   * registers: 192 accumulators as before; A fragments are three quads per tile, so they are requested ONE tile ahead of
+//     their MFMAs (24 VGPRs in flight) instead of two tiles at a time;
+//   * the chained third GEMM cannot keep the whole new residual stream pre-split (16 k-steps x 3 planes = 192 VGPRs): the B
+//     fragment of a k-step is split from the fp32 registers when it is needed, once per 128-row block of C3 (~50 VALU
+//     operations beside 24 MFMAs).
+// Per-wave patches for the epilogues live behind the ring (the 28 KiB slots leave no room above a 24 KiB tile).
+// =====================================================================================
+constexpr int M6_KT = 16;
+constexpr int M6_A1 = 3 * 2 * M_HC * 16;                      // 12 KiB
+constexpr int M6_SLOT = M6_A1 + M6_KT * M_BT * 4;             // 28 KiB
+constexpr int M6_T1 = M_D / M6_KT, M6_T2 = M_HC / M6_KT, M6_T3 = M_D / 32;  // 16 fc1 steps, 8 fc2 steps per chunk, 8 W3 steps per block
+constexpr int M6_PATCH = M_S * M6_SLOT;                       // 8 waves x 4 KiB
+constexpr int M6_SMEM = M6_PATCH + M_NW * 4096 + 4096;        // + fc1 bias
+static_assert(3 * 2 * M_D * 16 <= M6_SLOT && 3 * 4 * M_HC * 16 <= M6_SLOT, "fc2 / W3 tiles fit a ring slot");
+
+template <bool TANH, int EPI3>
+__global__ __launch_bounds__(64 * M_NW, 2) void mlp_fused6_kernel(GemmArgs g) {
+  typedef SplitMode<0> SM;
+  typedef bf16x8 svec;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn6[];
+  unsigned char* const smem = smem_dyn6;
+  float* s_b1 = reinterpret_cast<float*>(smem + M6_PATCH + M_NW * 4096);  // fc1 bias, [N] (N <= 1024)
+
+  const unsigned nwg = gridDim.x;
+  unsigned bid = blockIdx.x;
+  {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t t_blk = (int64_t)bid * M_BT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_w = wave * 32;
+  const int i = lane & 31, h = lane >> 5;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int n_hc = g.N / M_HC;
+  const int K8 = g.K >> 3, N8 = g.N >> 3;
+
+  for (int j = tid; j < g.N; j += 64 * M_NW) s_b1[j] = g.bias[j];
+  float rs, nm;
+  {
+    const int64_t t = t_blk + t_w + i;
+    float m = g.mean[t], r = g.rstd[t];  // sum / sum of squares over the K channels (fused statistics)
+    m = m / (float)g.K;
+    const float var = fmaxf(r / (float)g.K - m * m, 0.f);
+    r = 1.0f / sqrtf(var + g.ln_eps);
+    rs = r;
+    nm = -m * r;
+  }
+
+  const uint32_t voff = lane * 16;
+  const uint32_t xoff = (uint32_t)(4 * h) * (uint32_t)g.Tp + (uint32_t)(t_blk + t_w + i);
+  auto x_at = [&](const float* xbase, int row_u) -> float { return (xbase + (int64_t)row_u * g.Tp)[xoff]; };
+  auto x_base = [&]() -> const float* {
+    const float* p = g.X;
+    asm volatile("" : "+s"(p));
+    return p;
+  };
+  // ---- LDS-DMA pieces (1 KiB each; piece number q = wave + 8 idx of the tile) ----
+  //   fc1 step s:  q < 12: A1 piece [plane][octet][64 hidden]; 12 <= q < 28: X row q - 12      (4 / 3 per wave)
+  //   fc2 step s:  24 pieces [plane][octet][4 x 64 outputs]                                     (3 per wave)
+  auto issue_one = [&](int hc, int s, int slot, int idx) {
+    const uint32_t base = lds0 + slot * M6_SLOT;
+    const int q = wave + 8 * idx;
+    if (s < M6_T1) {
+      if (q < 12) {
+        const int pl = q >> 2, o = (q >> 1) & 1, seg = q & 1;
+        const unsigned short* a1 = g.Wp + ((((int64_t)pl * K8 + 2 * s + o) * g.N + hc * M_HC + seg * 64) << 3);
+        glds16_s(a1, voff, base + ((pl * 2 + o) * M_HC + seg * 64) * 16);
+      } else if (q < 28) {
+        const int row = q - 12;
+        glds16_s(g.X + (int64_t)(M6_KT * s + row) * g.Tp + t_blk, voff, base + M6_A1 + row * 1024);
+      }
+    } else {
+      const int pl = q >> 3, o = (q >> 2) & 1, seg = q & 3;
+      const int64_t oct = 2 * ((int64_t)hc * M6_T2 + (s - M6_T1)) + o;
+      const unsigned short* a2 = g.Wp2 + ((((int64_t)pl * N8 + oct) * M_D + seg * 64) << 3);
+      glds16_s(a2, voff, base + ((pl * 2 + o) * M_D + seg * 64) * 16);
+    }
+  };
+  const int n_p1 = wave < 4 ? 4 : 3;  // wave-uniform
+  auto n_pieces = [&](int s) { return s < M6_T1 ? n_p1 : 3; };
+  auto issue_all = [&](int hc, int s, int slot) {
+    for (int idx = 0; idx < n_pieces(s); ++idx) issue_one(hc, s, slot, idx);
+  };
+
+  f32x16 acc1[4], acc2[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[a][e] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc1[a][e] = 0.f;
+  float mx_unused = 0.f;
+
+  int cur = 0;
+  auto step_end = [&](int n_new) {  // the next step's tile has landed once only this step's own loads are outstanding
+    if (n_new == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n_new == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = cur + 1 == M_S ? 0 : cur + 1;
+  };
+  // one tile's A fragments: three planes, `OCTS` octets per plane in the slot, octet `o` of this lane half
+  auto load3 = [&](u32x4 (&f)[3], uint32_t addr, auto off0, auto plane_stride) {
+    constexpr int O = decltype(off0)::value, PS = decltype(plane_stride)::value;
+    f[0] = lds_read_b128<O>(addr);
+    f[1] = lds_read_b128<O + PS>(addr);
+    f[2] = lds_read_b128<O + 2 * PS>(addr);
+  };
+  auto wait3 = [&](auto n, u32x4 (&f)[3]) {
+    constexpr int N = decltype(n)::value;
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]) : "n"(N));
+  };
+  auto as_vec = [&](const u32x4 (&f)[3], svec (&o)[3]) {
+    o[0] = __builtin_bit_cast(svec, f[0]);
+    o[1] = __builtin_bit_cast(svec, f[1]);
+    o[2] = __builtin_bit_cast(svec, f[2]);
+  };
+
+  issue_all(0, 0, 0);
+  issue_all(0, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int hc = 0; hc < n_hc; ++hc) {
+    // ---------------- fc1: 16 steps of 16 channels ----------------
+    for (int kt = 0; kt < M6_T1; ++kt) {
+      const int ns = kt + 2, nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+      const int n_new = n_pieces(ns);
+      const uint32_t aA = lds0 + cur * M6_SLOT + (h * M_HC + i) * 16;
+      const uint32_t aB = lds0 + cur * M6_SLOT + M6_A1 + ((8 * h) * M_BT + t_w + i) * 4;
+      f32x2 xb[4];
+      u32x4 af[2][3];
+      static_for<4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        xb[j] = lds_read2st64<4 * (2 * j), 4 * (2 * j + 1)>(aB);
+      });
+      load3(af[0], aA, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * M_HC * 16>{});
+      lds_wait<3>(xb[0], xb[1], xb[2], xb[3]);
+      float x[8];
+      svec bs[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[2 * j] = fmaf(xb[j][0], rs, nm);
+        x[2 * j + 1] = fmaf(xb[j][1], rs, nm);
+      }
+      SM::split_mx(x, bs, mx_unused);
+      static_for<4>([&](auto mc) {
+        constexpr int mi = decltype(mc)::value;
+        if constexpr (mi + 1 < 4)
+          load3(af[(mi + 1) & 1], aA, std::integral_constant<int, (mi + 1) * 32 * 16>{}, std::integral_constant<int, 2 * M_HC * 16>{});
+        if constexpr (mi == 2) {  // every LDS read of this tile is in flight: the barrier sits in front of the last two groups
+          wait3(std::integral_constant<int, 0>{}, af[1]);
+          wait3(std::integral_constant<int, 0>{}, af[0]);
+          step_end(n_new);
+        } else if constexpr (mi + 1 < 4) {
+          wait3(std::integral_constant<int, 3>{}, af[mi & 1]);
+        } else {
+          wait3(std::integral_constant<int, 0>{}, af[mi & 1]);
+        }
+        svec a3[3];
+        as_vec(af[mi & 1], a3);
+        acc1[mi] = SM::mma(a3, bs, acc1[mi]);
+        if constexpr (mi < 2) {  // the DMA pieces of the tile two steps ahead, two behind each of the first two groups
+          __builtin_amdgcn_sched_barrier(0);
+          if (2 * mi < n_new) issue_one(hc, ns, nslot, 2 * mi);
+          if (2 * mi + 1 < n_new) issue_one(hc, ns, nslot, 2 * mi + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    }
+    // ---------------- fc2 over this chunk's 128 hidden units: 8 steps of 16 (= half a fc1 tile row) ----------------
+    static_for<M6_T2>([&](auto kc) {
+      constexpr int s2 = decltype(kc)::value, mi = s2 >> 1, q = s2 & 1;
+      const bool same = s2 + 2 < M6_T2;
+      const int ns = same ? M6_T1 + s2 + 2 : s2 + 2 - M6_T2, nhc = same ? hc : hc + 1;
+      const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+      const int n_new = nhc < n_hc ? n_pieces(ns) : 0;
+      // B fragment: H = gelu(acc1 + b1) of hidden rows 32 mi + 16 q + 4 h + {0..3, 8..11}
+      const float* bp = s_b1 + hc * M_HC + mi * 32 + 16 * q + 4 * h;
+      const float4 b_lo = *reinterpret_cast<const float4*>(bp), b_hi = *reinterpret_cast<const float4*>(bp + 8);
+      const float bb[8] = {b_lo.x, b_lo.y, b_lo.z, b_lo.w, b_hi.x, b_hi.y, b_hi.z, b_hi.w};
+      float hv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fmaf(acc1[mi][8 * q + j], g.w_inv_scale, bb[j]);
+        hv[j] = TANH ? gelu_tanh(v) : gelu_erf(v);
+      }
+      svec hf[3];
+      SM::split_mx(hv, hf, mx_unused);
+      const uint32_t aW = lds0 + cur * M6_SLOT + (h * M_D + i) * 16;
+      u32x4 wf[2][3];
+      load3(wf[0], aW, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * M_D * 16>{});
+      static_for<8>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b + 1 < 8)
+          load3(wf[(b + 1) & 1], aW, std::integral_constant<int, (b + 1) * 32 * 16>{}, std::integral_constant<int, 2 * M_D * 16>{});
+        if constexpr (b == 6) {
+          wait3(std::integral_constant<int, 0>{}, wf[1]);
+          wait3(std::integral_constant<int, 0>{}, wf[0]);
+          step_end(n_new);
+        } else if constexpr (b + 1 < 8) {
+          wait3(std::integral_constant<int, 3>{}, wf[b & 1]);
+        } else {
+          wait3(std::integral_constant<int, 0>{}, wf[b & 1]);
+        }
+        svec a3[3];
+        as_vec(wf[b & 1], a3);
+        acc2[b] = SM::mma(a3, hf, acc2[b]);
+        if constexpr (b < 4) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (b < n_new) issue_one(nhc, ns, nslot, b);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      if constexpr (q == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[mi][e] = 0.f;  // tile consumed: ready for the next chunk
+      }
+    });
+  }
+
+  float* const patch = reinterpret_cast<float*>(smem + M6_PATCH) + wave * 1024;
+  if constexpr (EPI3 < 0) {
+    GemmArgs e = g;
+    e.bias = g.bias2;
+    e.w_inv_scale = g.w_inv_scale2;
+    e.N = M_D;
+    e.stats_store = 1;
+    const int ii = lane & 31, hh = lane >> 5;
+    gemm_epilogue_lds_core<EPI_BIAS_RES_STATS, 8, 1>(
+        e,
+        [&](int mi, int, float* p) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ii] = acc2[mi][r];
+        },
+        patch, 0, t_blk + t_w, lane);
+  } else {
+    // =============== third GEMM: C3 = epi3(W3 . LayerNorm(x_new)), x_new = x + acc2 + b2 ===============
+    const int n_mb = g.N3 / M_HC;
+    // W3 tile of one step: 32 deep, [plane][4 octets][128 rows][8] = 24 KiB at the slot base; 24 pieces, 3 per wave
+    auto issue3 = [&](int mb, int s3, int slot, int idx) {
+      const int q = wave + 8 * idx, pl = q >> 3, o = (q >> 1) & 3, seg = q & 1;
+      const unsigned short* a3 = g.Wp3 + ((((int64_t)pl * K8 + 4 * s3 + o) * g.N3 + mb * M_HC + seg * 64) << 3);
+      glds16_s(a3, voff, lds0 + slot * M6_SLOT + ((pl * 4 + o) * M_HC + seg * 64) * 16);
+    };
+#pragma unroll
+    for (int idx = 0; idx < 3; ++idx) issue3(0, 0, 0, idx);
+#pragma unroll
+    for (int idx = 0; idx < 3; ++idx) issue3(0, 1, 1, idx);
+    const int64_t tcol = t_blk + t_w + i;
+    const float* xres = x_base();
+    float s_sum = 0.f, s_sq = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int row0 = 32 * tl + 8 * gq + 4 * h;
+        const float4 b4 = *reinterpret_cast<const float4*>(g.bias2 + row0);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xo = x_at(xres, 32 * tl + 8 * gq + r);
+          const float xn = fmaf(acc2[tl][4 * gq + r], g.w_inv_scale2, bb[r]) + xo;
+          acc2[tl][4 * gq + r] = xn;
+          s_sum += xn;
+          s_sq = fmaf(xn, xn, s_sq);
+        }
+      }
+    }
+    s_sum += __shfl_xor(s_sum, 32, 64);
+    s_sq += __shfl_xor(s_sq, 32, 64);
+    if (h == 0) {
+      g.st_sum[tcol] = s_sum;
+      g.st_sq[tcol] = s_sq;
+    }
+    {
+      const int rr = lane >> 3, c4 = (lane & 7) * 4;
+      float* cst = g.C;
+      asm volatile("" : "+s"(cst));
+#pragma unroll
+      for (int tl = 0; tl < 8; ++tl) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc2[tl][r];
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) {
+          const float4 v = *reinterpret_cast<const float4*>(patch + (p4 * 8 + rr) * 32 + c4);
+          *reinterpret_cast<float4*>(cst + (int64_t)(32 * tl + p4 * 8 + rr) * g.Tp + t_blk + t_w + c4) = v;
+        }
+      }
+    }
+    float rs3, nm3;
+    {
+      const float m = s_sum / (float)M_D;
+      const float var = fmaxf(s_sq / (float)M_D - m * m, 0.f);
+      rs3 = 1.0f / sqrtf(var + g.ln_eps);
+      nm3 = -m * rs3;
+    }
+    f32x16 acc3[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc3[a][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur = 0;
+    GemmArgs e3 = g;
+    e3.bias = g.bias3;
+    e3.w_inv_scale = g.w_inv_scale3;
+    e3.N = g.N3;
+    e3.C = g.C3;
+    bool after_epi = false;
+    for (int mb = 0; mb < n_mb; ++mb) {
+      static_for<M6_T3>([&](auto sc3) {
+        constexpr int s3 = decltype(sc3)::value;
+        const bool same = s3 + 2 < M6_T3;
+        const int ns3 = same ? s3 + 2 : s3 + 2 - M6_T3, nmb = same ? mb : mb + 1;
+        const int nslot = cur + 2 >= M_S ? cur + 2 - M_S : cur + 2;
+        const bool more = nmb < n_mb;
+        static_for<2>([&](auto ssc) {
+          constexpr int ss = decltype(ssc)::value, j = 2 * s3 + ss;  // k-step j: channels 16 j .. 16 j + 15 (permuted order)
+          const uint32_t aA = lds0 + cur * M6_SLOT + ((2 * ss + h) * M_HC + i) * 16;
+          u32x4 af[2][3];
+          load3(af[0], aA, std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * M_HC * 16>{});
+          float xv[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) xv[r] = fmaf(acc2[j >> 1][8 * (j & 1) + r], rs3, nm3);
+          svec xs[3];
+          SM::split_mx(xv, xs, mx_unused);
+          static_for<4>([&](auto mc) {
+            constexpr int mi = decltype(mc)::value;
+            if constexpr (mi + 1 < 4) {
+              load3(af[(mi + 1) & 1], aA, std::integral_constant<int, (mi + 1) * 32 * 16>{}, std::integral_constant<int, 4 * M_HC * 16>{});
+              wait3(std::integral_constant<int, 3>{}, af[mi & 1]);
+            } else {
+              wait3(std::integral_constant<int, 0>{}, af[mi & 1]);
+            }
+            svec a3[3];
+            as_vec(af[mi & 1], a3);
+            acc3[mi] = SM::mma(a3, xs, acc3[mi]);
+            if constexpr (ss == 0 && mi < 3) {  // the three DMA pieces of the tile two steps ahead
+              __builtin_amdgcn_sched_barrier(0);
+              if (more) issue3(nmb, ns3, nslot, mi);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+        });
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after_epi) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");  // 16 stores of the block epilogue + this step's 3 pieces
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        after_epi = false;
+        __syncthreads();
+        cur = cur + 1 == M_S ? 0 : cur + 1;
+      });
+      after_epi = true;
+      gemm_epilogue_lds_core<EPI3, 4, 1>(
+          e3,
+          [&](int mi, int, float* p) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = acc3[mi][r];
+          },
+          patch, mb * M_HC, t_blk + t_w, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[a][r] = 0.f;
+    }
+  }
+}
+
 // k order of the fused MLP kernel's register-fed GEMMs.  (A v_mfma_f32_16x16x32_f16 form of the kernel with a
 // 32-group permutation was measured 15 % slower -- commit 8d24a79, profiles/r02_mlp_shape16_and_valu_ablations.json.)
 int mlp_fused_perm(int k) { return (k & ~15) + mlp_perm16(k & 15); }
 
 int launch_mlp_fused(hipStream_t st, const GemmArgs& g) {
-  DC_REQUIRE(g.split_mode == 1 && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the fp16x3 planes of fc1 and fc2");
+  DC_REQUIRE((g.split_mode == 0 || g.split_mode == 1) && g.Wp && g.Wp2 && g.bias2, "fused MLP needs the split planes of fc1 and fc2");
   DC_REQUIRE(g.K == M_D && g.N % M_HC == 0 && g.N <= 1024 && g.Tp % M_BT == 0, "fused MLP: d_model 256, d_inner <= 1024");
   DC_REQUIRE(g.X == g.R && g.mean && g.rstd && g.st_sum && g.st_sq, "fused MLP updates the residual stream in place");
   if (g.Wp3)
     DC_REQUIRE(g.bias3 && g.C3 && g.N3 % M_HC == 0 && g.N3 <= 1024 && (g.epi3 == EPI_BIAS || (g.epi3 == EPI_BIAS_RELU_Q && g.q)),
                "fused MLP: third GEMM needs bias3, C3, N3 % 128 == 0 and epi3 in {EPI_BIAS, EPI_BIAS_RELU_Q}");
   const dim3 grid((unsigned)(g.Tp / M_BT)), block(64 * M_NW);
-  auto launch = [&](auto tanh_c, auto epi_c) {
-    hipLaunchKernelGGL((mlp_fused_kernel<decltype(tanh_c)::value, decltype(epi_c)::value>), grid, block, 0, st, g);
+  auto launch = [&](auto tanh_c, auto epi_c) -> int {
+    if (g.split_mode == 0) {  // strict arithmetic: the three-plane kernel (dynamic LDS: 120 KiB)
+      DC_SET_MAX_SMEM_ONCE_PER_DEVICE((&mlp_fused6_kernel<decltype(tanh_c)::value, decltype(epi_c)::value>), M6_SMEM);
+      hipLaunchKernelGGL((mlp_fused6_kernel<decltype(tanh_c)::value, decltype(epi_c)::value>), grid, block, M6_SMEM, st, g);
+    } else {
+      hipLaunchKernelGGL((mlp_fused_kernel<decltype(tanh_c)::value, decltype(epi_c)::value>), grid, block, 0, st, g);
+    }
+    return DC_OK;
   };
-  auto by_epi = [&](auto tanh_c) {
-    if (!g.Wp3) launch(tanh_c, std::integral_constant<int, -1>{});
-    else if (g.epi3 == EPI_BIAS) launch(tanh_c, std::integral_constant<int, EPI_BIAS>{});
-    else launch(tanh_c, std::integral_constant<int, EPI_BIAS_RELU_Q>{});
+  auto by_epi = [&](auto tanh_c) -> int {
+    if (!g.Wp3) return launch(tanh_c, std::integral_constant<int, -1>{});
+    if (g.epi3 == EPI_BIAS) return launch(tanh_c, std::integral_constant<int, EPI_BIAS>{});
+    return launch(tanh_c, std::integral_constant<int, EPI_BIAS_RELU_Q>{});
   };
-  if (g.gelu_tanh) by_epi(std::true_type{});
-  else by_epi(std::false_type{});
+  const int rc = g.gelu_tanh ? by_epi(std::true_type{}) : by_epi(std::false_type{});
+  if (rc) return rc;
   DC_LAUNCH_CHECK();
   return DC_OK;
 }

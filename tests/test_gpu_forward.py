@@ -298,12 +298,14 @@ def test_long_convolution_forms_error_vs_float64(hip_lib):
         model.close()
 
 
+@pytest.mark.parametrize("mode", ["fp16x3", "bf16x6"])
 @pytest.mark.parametrize("d_inner,gelu", [(1024, "tanh"), (512, "tanh"), (1024, "none"), (384, "tanh")])
-def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
-    """fp16x3: the fused MLP kernel (fc1 -> GELU -> fc2 with the hidden activation in registers, fc2's k order
-    permuted on the host) against the two-GEMM form of the same build and against the oracle, for the reference
-    shape, a narrower MLP (4 hidden chunks), the erf GELU, and a width the fused kernel does not take
-    (d_inner % 128 != 0 -> the switch is a no-op and both runs use the two-kernel form)."""
+def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu, mode):
+    """The fused MLP kernel (fc1 -> GELU -> fc2 with the hidden activation in registers, fc2's k order permuted on the
+    host) against the two-GEMM form of the same build and against the oracle, for the reference shape, a narrower MLP
+    (4 hidden chunks), the erf GELU, and a width the fused kernel does not take (d_inner % 128 != 0 -> the switch is a
+    no-op and both runs use the two-kernel form) -- in the default 2 x fp16 split AND, since round 6, in the strict
+    error-free 3 x bf16 split (mlp_fused6_kernel: the mode the range guard falls back to)."""
     from deepchopper_amd import ops
     from deepchopper_amd.weights import HyenaDNAConfig, synthetic_state_dict
     from oracle import forward_ref as fr
@@ -312,6 +314,7 @@ def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     sd = synthetic_state_dict(11, cfg)
     model = ops.HipModel(sd, cfg)
     assert model.gemm_mode == "fp16x3"
+    model.set_gemm_mode(mode)
     rng = np.random.default_rng(d_inner)
     ids, q = _inputs(rng, 5, 333)
     d_ids, d_q = ops.to_device(ids), ops.to_device(q)
@@ -340,6 +343,9 @@ def test_mlp_fusion_matches_two_kernel_form(hip_lib, d_inner, gelu):
     assert np.abs(fused - plain).max() < 5e-5 * scale  # same split arithmetic, different summation order only
     assert np.abs(chained - plain).max() < 5e-5 * scale
     assert model.overflow() == 0
+    # identical labels wherever the margin exceeds the summation-order noise
+    sure = np.abs(plain[..., 1] - plain[..., 0]) > 1e-4 * scale
+    assert np.array_equal((chained[..., 1] > chained[..., 0])[sure], (plain[..., 1] > plain[..., 0])[sure])
 
 
 @pytest.mark.parametrize("B,L", [(2, 2001), (1, 5000), (1, 10001), (2, 20000), (1, 32768), (1, 32769)])
