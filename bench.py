@@ -46,11 +46,13 @@ ROOFLINE_KERNELS = {
     "mlp_inproj_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS> (fc1 -> GELU -> fc2 -> +residual -> LayerNorm -> next block's in_proj, fp16x3)",
                    "traffic_bpt": (2 * 9622134.7 + 8241858.0) * 1024 / 2056448, "source": "profiles/r05_pmc_hbm_traffic.json"},
+        "bf16x6": {"kernel": "mlp_fused6_kernel<true,EPI_BIAS> (the same chain in the error-free 3 x bf16 split: six MFMAs per fp32-equivalent FMA)"},
         "algorithmic_bpt": 2 * 1024 + 3 * 1024 + 16,  # residual stream in and out + in_proj output (fp32) + statistics
     },
     "mlp_head1_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS_RELU_Q> (last block's MLP + head linear1, fp16x3)",
                    "traffic_bpt": (2 * 9711070.4 + 10298306.0) * 1024 / 2056448, "source": "profiles/r05_pmc_hbm_traffic.json"},
+        "bf16x6": {"kernel": "mlp_fused6_kernel<true,EPI_BIAS_RELU_Q> (last block's MLP + head linear1, 3 x bf16 split)"},
         "algorithmic_bpt": 2 * 1024 + 4 * 1024 + 20,
     },
     "mlp_fused": {

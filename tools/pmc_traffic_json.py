@@ -26,6 +26,8 @@ fetch, write = per_call(tag + "_pmc_fetch", "FETCH_SIZE"), per_call(tag + "_pmc_
 ALG = {  # algorithmic HBM bytes per token of the kernels of a step
     "mlp_fused_kernel<true, 0>": ("mlp_fused_kernel<true,EPI_BIAS>: MLP + next in_proj", 5136),
     "mlp_fused_kernel<true, 3>": ("mlp_fused_kernel<true,EPI_BIAS_RELU_Q>: MLP + head linear1", 6164),
+    "mlp_fused6_kernel<true, 0>": ("mlp_fused6_kernel<true,EPI_BIAS>: MLP + next in_proj, strict bf16x6", 5136),
+    "mlp_fused6_kernel<true, 3>": ("mlp_fused6_kernel<true,EPI_BIAS_RELU_Q>: MLP + head linear1, strict bf16x6", 6164),
     "gemm6_kernel<5, false, 1>": ("gemm6_kernel<EPI_HEAD2_FUSED,false,1>: head linear2+3", 8208),
     "gemm6_kernel<6, false, 1>": ("gemm6_kernel<EPI_BIAS_RES_STATS,false,1>: out_proj", 3088),
     "hyena4_kernel<1, false, 0>": ("hyena4_kernel<1,false,0>: warp-specialised block-Toeplitz long convolution (layers 1-3)", 4096),
