@@ -196,6 +196,47 @@ def test_chop_driver_matches_oracle(env, tmp_path):
     assert int(os.path.basename(out).split(".")[2].replace("record", "")) == len(got)
 
 
+@pytest.mark.parametrize("chunk", [0, 1])
+def test_chop_over_the_reference_pt_directories_equals_the_oracle(hip_lib, tmp_path, chunk):
+    """`deepchopper chop <dir> reads.fq` over the REFERENCE's own prediction files (tests/golden/pt/chunk{0,1}:
+    its tests/data/eval, the files its loader is pinned on, src/smooth/predict.rs:323-330) -- read natively (chunk1's older
+    int8 layout included), smoothed on the GPU, split and written by the host library -- against the oracle's chop_read on the
+    same 36 reads, byte for byte.  The FASTQ that produced the files is not in the reference's repository: it is synthesised
+    from their `seq` / `id` rows (letters of the unmasked positions; a constant quality)."""
+    import gzip
+
+    import torch
+
+    from deepchopper_amd import rs_api
+    from deepchopper_amd.chop import chop
+    from oracle import dc_oracle as o
+
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pt", f"chunk{chunk}")
+    records, preds = [], {}
+    for name in sorted(os.listdir(d)):
+        t = {k: v.numpy() for k, v in torch.load(os.path.join(d, name), map_location="cpu", weights_only=True).items()}
+        got = o.load_predicts_from_batch({"prediction": t["prediction"], "target": t["target"].astype(np.int64), "seq": t["seq"].astype(np.int64),
+                                          "id": t["id"].astype(np.int64)})
+        for rid, p in got.items():
+            preds[rid] = p
+            records.append((rid.encode(), p.seq.encode(), b"I" * len(p.seq)))
+    assert len(records) == 36
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(b"".join(b"@" + i + b" ch=7\n" + s + b"\n+\n" + q + b"\n" for i, s, q in records))
+    store = rs_api.LabelStore.load(d, threads=2)
+    assert store.fallback_files == [] and len(store) == 36
+    out = chop([d], str(fq), output_prefix=str(tmp_path / "out"), threads=2)
+    want = []
+    n_chopped = 0
+    for rid, s, q in records:
+        recs = o.chop_read(preds[rid.decode()], rid, s, q, fq_header=rid + b" ch=7")
+        n_chopped += len(recs) != 1 or recs[0][0] != rid + b" ch=7"
+        want += [b"@" + i + b"\n" + rs + b"\n+\n" + rq + b"\n" for i, rs, rq in recs]
+    assert gzip.open(out, "rb").read() == b"".join(want)
+    assert os.path.basename(out) == f"out.36pd.{len(want)}record.chop.fq.gz"
+    assert n_chopped > 0, "the reference's real predictions must chop something"
+
+
 def test_native_chop_equals_the_per_record_form(env, tmp_path, monkeypatch):
     """`chop` (native `.pt` loader -> one GPU smoothing launch per chunk -> dc_chop_write_chunk) against its per-record form
     (DC_CHOP_PYTHON=1: `chop_chunk`, the line-by-line restatement of process_chunk, src/bin/predict.rs:130-192) on the same
