@@ -270,7 +270,11 @@ int dc_forward_shared_prefix(dc_model* m, void* stream, const void* d_input_ids,
  *     what it costs without padding (O(n^2) / O(n log n) in the READ's length, not the batch's longest).  Same
  *     mathematics, another summation order: logits agree with the exact form to fp32 rounding (~1e-5 on O(1) logits;
  *     tests hold it to 2e-4), not bit for bit.
- * $DC_PREFIX_MODE = exact | linear sets the initial mode of a handle. */
+ * $DC_PREFIX_MODE = exact | linear sets the initial mode of a handle.  Who defaults to what: a handle created through this ABI
+ * starts in mode 1; the Python pipeline (deepchopper_amd/predict.py: `predict`, `predict --chop --reference-batching`, the
+ * `.pt` writer) switches its handle to mode 2 unless $DC_PREFIX_MODE says exact -- measured over a 32 600-token pad run and
+ * 20 seeds of nanopore-like batches, mode 2 is the closer of the two to a float64 evaluation (<= 1.0e-4 against <= 1.2e-4 for
+ * the padded launch; they differ from each other by <= 1.5e-4: tests/test_gpu_forward.py::test_linear_prefix_form_*). */
 int dc_model_set_prefix_mode(dc_model* m, int32_t mode);
 
 /* Wavefronts of dc_forward_shared_prefix's copy pass that met a declared pad position not holding

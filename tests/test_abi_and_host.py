@@ -417,10 +417,18 @@ def test_pt_writer_flush_block_waits_for_one_launch_only():
     from deepchopper_amd.predict import PtWriter
 
     class Event:
+        """A copy that lands when it is WAITED for (polled a second time: predict.wait_event polls query() between sleeps;
+        the loop's own "has it landed?" look is one poll)."""
+
         def __init__(self):
-            self.done, self.waited = False, 0
+            self.done, self.waited, self.polls = False, 0, 0
 
         def query(self):
+            if self.done:
+                return True
+            self.polls += 1
+            if self.polls >= 2:
+                self.done, self.waited = True, self.waited + 1
             return self.done
 
         def synchronize(self):
@@ -467,9 +475,9 @@ def test_pt_writer_flush_block_waits_for_one_launch_only():
         w._flush(block=True)
         assert [e.waited for e in events] == [1, 0, 0, 0, 0] and len(w._staged) == 4
         assert w._io.lib().calls == [(0, 7, 1)]
-        events[2].done = True  # its copy has landed: goes along with the oldest, and the loop stops at the fourth
+        events[2].done = True  # its copy has landed: goes along with the oldest (unwaited), and the loop stops at the fourth
         w._flush(block=True)
-        assert [e.waited for e in events] == [1, 1, 1, 0, 0] and len(w._staged) == 2
+        assert [e.waited for e in events] == [1, 1, 0, 0, 0] and len(w._staged) == 2
         assert w._io.lib().calls == [(0, 7, 1), (0, 8, 1), (0, 9, 1)]
         w._pending.clear()
         w._staged.extend((ev, (b"/nowhere", 0, 20 + k, i32, i32, i32, i64, 0, 0, b"", i64, np.zeros(1, np.uint8)), None, Pinned())
