@@ -231,7 +231,7 @@ def predict_chop_stream(pipe, chunks, writer: BgzfWriter, chop_type: str = "all"
 def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | None = None, threads: int = 2,
                  output_chopped_seqs: bool = False, max_reads: int = 8192, max_tokens: int = 2_000_000,
                  chunks=None, level: int = 6, part_path: str | None = None, reference_batch: int | None = None,
-                 mark_sub_batches: bool = False):
+                 mark_sub_batches: bool = False, on_batch=None):
     """`deepchopper predict` + `deepchopper chop` as one streaming pass (no `.pt` files).
 
     reference_batch = B: the reads run in the reference's batches of B (`predict -b B`: consecutive reads, left-padded per
@@ -259,10 +259,10 @@ def predict_chop(fq: str, pipe, chop_type: str = "all", output_prefix: str | Non
             if chunks is None:
                 with FastqReader(fq, full_header=True, strict_four_line=True) as rd:
                     src = rd.chunks(reference_batch, 1 << 30) if ref else rd.chunks(max_reads, max_tokens)
-                    n_reads, n_out = predict_chop_stream(pipe, batches(src), fh, chop_type, output_chopped_seqs,
+                    n_reads, n_out = predict_chop_stream(pipe, batches(src), fh, chop_type, output_chopped_seqs, on_batch=on_batch,
                                                          reference_padding=ref, mark_sub_batches=mark_sub_batches)
             else:
-                n_reads, n_out = predict_chop_stream(pipe, batches(chunks), fh, chop_type, output_chopped_seqs,
+                n_reads, n_out = predict_chop_stream(pipe, batches(chunks), fh, chop_type, output_chopped_seqs, on_batch=on_batch,
                                                      reference_padding=ref, mark_sub_batches=mark_sub_batches)
         LAST_WRITER_STATS.update({"deflate_cpu_s": fh.deflate_cpu_s, "bgzf_bytes": fh.data_bytes, "threads": threads})
         if part_path:  # the writer is closed: the chunk offsets are known

@@ -238,9 +238,20 @@ def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24, reference
         os.remove(warm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        final, n_in, n_out = predict_chop(path, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000, reference_batch=reference_batch)
+        marks = [(0, t0)]
+
+        def mark(res):
+            marks.append((marks[-1][0] + int(res["lengths"].shape[0]), time.perf_counter()))
+
+        final, n_in, n_out = predict_chop(path, pipe, threads=threads, max_reads=8192, max_tokens=2_000_000, reference_batch=reference_batch,
+                                          on_batch=mark)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+
+        def rate_between(lo, hi):  # reads/s between the first launch at or behind `lo` reads and the last one at or before `hi`
+            a = next(m for m in marks if m[0] >= lo)
+            b = next(m for m in reversed(marks) if m[0] <= hi)
+            return round((b[0] - a[0]) / (b[1] - a[1]), 1) if b[0] > a[0] else None
         out = {"workload": "configs[4] flow on one GPU: nanopore-like reads (log-normal lengths, ONT headers, adapters planted), plain "
                            ".fastq.gz -> parallel inflate -> predict -> chop (src/bin/predict.rs:130-192) -> BGZF, no .pt in between" +
                            ("" if reference_batch is None else f"; the reads in the reference's left-padded batches of {reference_batch} "
@@ -249,7 +260,9 @@ def gz_chop_leg(n_reads: int, threads: int = 4, check_reads: int = 24, reference
                "value": round(n_in / dt, 1), "unit": "reads/s", "Mbases_per_s": round(n_bases / dt / 1e6, 2), "reads": n_in,
                "mean_bp": round(n_bases / n_reads, 1), "seconds": round(dt, 3), "bgzf_threads": threads,
                "input_MB": round(os.path.getsize(path) / 1e6, 1), "output_MB": round(os.path.getsize(final) / 1e6, 1),
-               "generate_s": round(gen_s, 1)}
+               "generate_s": round(gen_s, 1),
+               # droop check inside the driver's own run: the rate over the first and the last third of the reads
+               "first_third_reads_per_s": rate_between(0, n_in // 3), "last_third_reads_per_s": rate_between(n_in - n_in // 3, n_in)}
         counts = _count_output(final)
         out.update(counts)
         check = {"records_match_driver_report": counts["records"] == n_out, "reads_in_match": n_in == n_reads,
