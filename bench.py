@@ -45,13 +45,13 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (no 
 ROOFLINE_KERNELS = {
     "mlp_inproj_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS> (fc1 -> GELU -> fc2 -> +residual -> LayerNorm -> next block's in_proj, fp16x3)",
-                   "traffic_bpt": (2 * 9622134.7 + 8241858.0) * 1024 / 2056448, "source": "profiles/r05_pmc_hbm_traffic.json"},
+                   "traffic_bpt": (2 * 9603326.1 + 8241858.0) * 1024 / 2056448, "source": "profiles/r06_pmc_hbm_traffic.json"},
         "bf16x6": {"kernel": "mlp_fused6_kernel<true,EPI_BIAS> (the same chain in the error-free 3 x bf16 split: six MFMAs per fp32-equivalent FMA)"},
         "algorithmic_bpt": 2 * 1024 + 3 * 1024 + 16,  # residual stream in and out + in_proj output (fp32) + statistics
     },
     "mlp_head1_fused": {
         "fp16x3": {"kernel": "mlp_fused_kernel<true,EPI_BIAS_RELU_Q> (last block's MLP + head linear1, fp16x3)",
-                   "traffic_bpt": (2 * 9711070.4 + 10298306.0) * 1024 / 2056448, "source": "profiles/r05_pmc_hbm_traffic.json"},
+                   "traffic_bpt": (2 * 9682701.4 + 10298306.0) * 1024 / 2056448, "source": "profiles/r06_pmc_hbm_traffic.json"},
         "bf16x6": {"kernel": "mlp_fused6_kernel<true,EPI_BIAS_RELU_Q> (last block's MLP + head linear1, 3 x bf16 split)"},
         "algorithmic_bpt": 2 * 1024 + 4 * 1024 + 20,
     },
@@ -62,7 +62,7 @@ ROOFLINE_KERNELS = {
     },
     "gemm_head2": {
         "fp16x3": {"kernel": "gemm6_kernel<EPI_HEAD2_FUSED,false,1> (head linear2+3, K=N=1024, fp16x3)",
-                   "traffic_bpt": (2 * 13699039.0 + 128528.0) * 1024 / 2056448, "source": "profiles/r05_pmc_hbm_traffic.json"},
+                   "traffic_bpt": (2 * 13669277.2 + 128528.0) * 1024 / 2056448, "source": "profiles/r06_pmc_hbm_traffic.json"},
         "bf16x6": {"kernel": "gemm6_kernel<EPI_HEAD2_FUSED,false,0> (head linear2+3, K=N=1024, bf16x6)",
                    "traffic_bpt": 14848064128.0 / 1025024, "source": "profiles/r01_pmc_hbm_traffic.json"},
         "f32": {"kernel": "gemm_kernel<EPI_BIAS_RES_RELU,false> (head linear2, K=N=1024, fp32 MFMA)"},
