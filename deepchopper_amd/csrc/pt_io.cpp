@@ -724,6 +724,7 @@ enum { ST_FLOAT = 0, ST_LONG, ST_CHAR, ST_INT, ST_SHORT, ST_BYTE, ST_DOUBLE, ST_
 
 struct PVal {
   enum Kind { NONE, MARK, INT, STR, GLOBAL, TUPLE, STORAGE, TENSOR, DICT, BOOL, OPAQUE } kind = NONE;
+  int depth = 0;            // nesting of TUPLEs below this value (bounded: destruction is recursive)
   int64_t i = 0;
   std::string s;            // STR; GLOBAL "module name"
   std::vector<PVal> items;  // TUPLE; DICT (key, value, key, value ...)
@@ -731,6 +732,16 @@ struct PVal {
 };
 
 bool parse_pickle(const uint8_t* p, size_t n, std::vector<std::pair<std::string, PtTensor>>& out) {
+  // torch.save's stream for this dict is ~500 bytes and nests three tuples deep; a "pickle" of megabytes or of thousands of
+  // nested tuples is not one of ours (and must not be allowed to recurse through the value destructors)
+  constexpr size_t kMaxPickle = 1u << 20;
+  constexpr int kMaxDepth = 16;
+  if (n > kMaxPickle) return false;
+  auto nest = [](std::vector<PVal>& items) {
+    int d = 0;
+    for (const PVal& x : items) d = std::max(d, x.depth);
+    return d + 1;
+  };
   std::vector<PVal> st;
   std::vector<PVal> memo;
   size_t i = 0;
@@ -755,6 +766,8 @@ bool parse_pickle(const uint8_t* p, size_t n, std::vector<std::pair<std::string,
     t.kind = PVal::TUPLE;
     t.items.assign(std::make_move_iterator(st.end() - (long)k), std::make_move_iterator(st.end()));
     st.resize(st.size() - k);
+    t.depth = nest(t.items);
+    if (t.depth > kMaxDepth) return false;
     st.push_back(std::move(t));
     return true;
   };
@@ -887,6 +900,8 @@ bool parse_pickle(const uint8_t* p, size_t n, std::vector<std::pair<std::string,
       case 't':
         v.kind = PVal::TUPLE;
         if (!pop_to_mark(v.items)) return false;
+        v.depth = nest(v.items);
+        if (v.depth > kMaxDepth) return false;
         st.push_back(std::move(v));
         break;
       case 0x85:

@@ -97,6 +97,17 @@ def test_native_reader_refuses_what_it_does_not_understand(tmp_path):
     assert [os.path.basename(f) for f in store.fallback_files] == ["glob.pt"]
 
 
+def test_hostile_pickles_are_refused_not_followed(tmp_path):
+    """A `data.pkl` of hundreds of thousands of nested tuples, or of megabytes, is not torch.save's ~500-byte stream: refused
+    before it can recurse through the parser's value destructors or grow its stack without bound."""
+    src = os.path.join(PT, "chunk0", "2.pt")
+    for name, pk in (("deep", b"\x80\x02" + b"(" * 200000 + b"t" * 200000 + b"."), ("huge", b"\x80\x02" + b"N0" * 900000 + b".")):
+        dst = tmp_path / f"{name}.pt"
+        _rewrite(src, dst, lambda n, b, pk=pk: pk if n.endswith("data.pkl") else b)
+        store = rs_api.LabelStore.load([str(dst)], threads=1)
+        assert len(store) == 0 and [os.path.basename(f) for f in store.fallback_files] == [f"{name}.pt"]
+
+
 def test_storage_offset_and_shared_storage(tmp_path):
     """Tensors that are views into one larger storage (non-zero storage offset): read where the pickle says they are."""
     src = os.path.join(PT, "chunk1", "1.pt")
