@@ -247,8 +247,8 @@ def main():
     ap.add_argument("--multi-legs", default="c3,c5", help="N > 1: file-fed legs run by all ranks -> `multi_gpu.*` ('' = none): c3 = one 2 kb "
                     "FASTQ in byte-range shards, c5 = one .fastq.gz through the node's single inflater + the same reads as BGZF shards, "
                     "both -> chopped BGZF spliced in input order (tools/bench_multi.py)")
-    ap.add_argument("--c3-reads-per-rank", type=int, default=60_000)
-    ap.add_argument("--c5-reads-per-rank", type=int, default=75_000)
+    ap.add_argument("--c3-reads-per-rank", type=int, default=100_000)
+    ap.add_argument("--c5-reads-per-rank", type=int, default=150_000)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -322,13 +322,14 @@ class ChunkFeeder:
                     if c is None:
                         return
                     write_chunk(fh, c)
-        except BrokenPipeError:
-            # the worker died (wait_ranks reports it): keep taking its share off the queue so that the reader thread,
-            # which deals round-robin through bounded queues, is not left blocked on this one
+        except BaseException as e:
+            # BrokenPipe: the worker died (wait_ranks / the rendezvous reports it).  Anything else (a rank that never opened its
+            # FIFO, a full disk behind a pipe ...) is this feeder's error.  Either way keep taking the rank's share off the queue:
+            # the reader thread deals round-robin through bounded queues and must not be left blocked on this one.
+            if not isinstance(e, BrokenPipeError):
+                self.error = self.error or e
             while self._queues[i].get() is not None:
                 pass
-        except BaseException as e:
-            self.error = self.error or e
         finally:
             self._leave_thread()
 
