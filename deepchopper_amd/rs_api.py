@@ -35,6 +35,7 @@ __all__ = [
     "encode_fq_path_to_tensor", "encode_fq_paths_to_tensor", "write_fq", "write_fq_parallel",
     "majority_voting", "get_label_region", "smooth_label_region", "summary_predict",
     "remove_intervals_and_keep_left", "id_list2seq", "load_predicts_from_batch_pt", "load_predicts_from_batch_pts",
+    "highlight_targets",
 ]
 
 MIN_READ_LEN = 150
@@ -464,6 +465,49 @@ class Predict:
 
     def qual_array(self):
         return [] if self.qual is None else [ord(c) - default.QUAL_OFFSET for c in self.qual]
+
+    def show_info(self, smooth_interval, text_width: int | None = None) -> str:
+        """smooth/predict.rs:127-146: id, the raw and the given smoothed regions, and the read with each set highlighted.
+        `prediction_region()` prints as Rust's `{:?}` of a `Vec<Range<usize>>` (`[3..9, 20..31]`), `smooth_interval` as a
+        `Vec<(usize, usize)>` (`[(3, 9)]`).  Host-only text formatting (no kernel behind it)."""
+        regions = self.prediction_region()
+        oreg = "[" + ", ".join(f"{s}..{e}" for s, e in regions) + "]"
+        sreg = "[" + ", ".join(f"({s}, {e})" for s, e in smooth_interval) + "]"
+        return (f"id: {self.id}\nprediction: {oreg}\nsmooth_intervals: {sreg}\n"
+                f"{highlight_targets(self.seq, regions, text_width)}\n\n{highlight_targets(self.seq, list(smooth_interval), text_width)}")
+
+
+def highlight_targets(sequence: str, targets, text_width: int | None = None) -> str:
+    """src/vis.rs:5-23 (PyO3 export `highlight_targets`): the target ranges of `sequence` in bold magenta, wrapped to
+    `text_width` (80) columns.  The reference builds it from two third-party crates that no test of its own pins: `colored`
+    (`.magenta().bold()` = `ESC[1;35m` ... `ESC[0m`) and `textwrap::wrap`, which measures display width -- escape sequences
+    count nothing -- and breaks a word longer than the line at the width.  A read has no blanks, so it is one such word: lines
+    of exactly `text_width` visible characters, escape sequences carried inline.  Restated from those published behaviours;
+    **parity unpinned** (the reference's `test_highlight` only prints)."""
+    width = 80 if text_width is None else int(text_width)
+    if width < 1:
+        raise ValueError("text_width must be positive")
+    on, off = "\x1b[1;35m", "\x1b[0m"
+    marks: dict[int, str] = {}  # escape sequences in front of visible position p (they take no room on a line)
+    last = 0
+    for s, e in targets:
+        if s < last or e < s or e > len(sequence):
+            raise IndexError("targets must be ascending, disjoint ranges inside the sequence")  # (Rust: a slice panic)
+        if e > s:
+            marks[s] = marks.get(s, "") + on
+            marks[e] = marks.get(e, "") + off
+        last = e
+    out, col = [], 0
+    for p in range(len(sequence) + 1):
+        if p in marks:          # zero width: stays on the line it is met on
+            out.append(marks[p])
+        if p < len(sequence):
+            if col == width:    # the line is full and another visible character comes: break in front of it
+                out.append("\n")
+                col = 0
+            out.append(sequence[p])
+            col += 1
+    return "".join(out)
 
 
 def predicts_from_batch(batch: dict, ignore_label: int = IGNORE_LABEL) -> dict[str, Predict]:

@@ -158,3 +158,28 @@ def test_write_fq_and_write_fq_parallel(tmp_path):
     r = recs[0]
     r.seq = "TTTT"
     assert (r.id, r.seq, r.qual) == ("r1", "TTTT", "IIII") and "TTTT" in repr(r)
+
+
+def test_highlight_targets_like_the_pyo3_export():
+    """src/vis.rs:5-23: bold magenta over the target ranges (colored's `.magenta().bold()`), wrapped at `text_width` VISIBLE
+    characters (textwrap breaks the one long word a read is; escape sequences take no room).  The reference's own test only
+    prints: parity unpinned, behaviour restated from the two crates."""
+    import re
+
+    from deepchopper_amd import rs_api
+
+    seq = "ATGCACTGACTGACATGCACTGACTGAC"
+    assert rs_api.highlight_targets(seq, [(0, 3), (10, 13)]) == "\x1b[1;35mATG\x1b[0mCACTGAC\x1b[1;35mTGA\x1b[0mCATGCACTGACTGAC"
+    strip = lambda x: re.sub(r"\x1b\[[0-9;]*m", "", x)  # noqa: E731
+    for w in (1, 5, 7, 27, 28, 80):
+        h = rs_api.highlight_targets(seq, [(0, 3), (10, 13), (20, 28)], w)
+        lines = h.split("\n")
+        assert strip(h).replace("\n", "") == seq
+        assert all(len(strip(l)) == w for l in lines[:-1]) and 0 < len(strip(lines[-1])) <= w
+        assert h.count("\x1b[1;35m") == 3 == h.count("\x1b[0m")
+    assert rs_api.highlight_targets("", []) == "" and rs_api.highlight_targets("ACGT", [(2, 2)]) == "ACGT"
+    with pytest.raises(IndexError):
+        rs_api.highlight_targets("ACGT", [(2, 9)])
+    import deepchopper
+
+    assert deepchopper.highlight_targets is rs_api.highlight_targets  # exported under the reference's import name too

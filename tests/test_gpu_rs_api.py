@@ -37,6 +37,12 @@ def test_smooth_label_region_and_predict_class(r):
     assert p.prediction_region() == [(50, 90), (120, 125)]
     assert p.smooth_and_select_intervals(21, 13, 20) == [(50, 90)]
     assert p.smooth_label(1) == lab and p.seq_len() == len(lab)
+    # Predict.show_info (smooth/predict.rs:127-146): Rust's {:?} of the two interval lists + the read highlighted twice
+    info = p.show_info(p.smooth_and_select_intervals(21, 13, 20), 60)
+    head = info.split("\n")
+    assert head[:3] == ["id: read1", "prediction: [50..90, 120..125]", "smooth_intervals: [(50, 90)]"]
+    plain = info.replace("\x1b[1;35m", "").replace("\x1b[0m", "")
+    assert plain.split("\n\n")[1].replace("\n", "") == "A" * len(lab) and info.count("\x1b[1;35m") == 3
     assert r.smooth_label_region([0, 1] * 200, 1, 1, 20) == []  # more than `approved` intervals -> []
     with pytest.raises(Exception, match="binary"):
         r.majority_voting([0, 2, 1], 3)
