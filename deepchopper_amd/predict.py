@@ -602,7 +602,7 @@ class PtWriter:
                 self._stream.wait_stream(torch.cuda.current_stream(dev))
             ops.pt_pack(logits, labels, ids_t, quals, table, self._d_out)
             pinned[:total].copy_(self._d_out[:total], non_blocking=True)
-            copied = torch.cuda.Event(blocking=True)  # (the writer's waits sleep, as the pipeline's do)
+            copied = torch.cuda.Event()  # (waited for by polling: wait_event)
             copied.record(self._stream)
         t2 = time.perf_counter()
         self.timers["pack_enqueue"] += t2 - t1
