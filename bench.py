@@ -386,6 +386,11 @@ def main():
             if rank == 0:
                 multi["c3_2kb_file_sharded"] = leg
         if "c5" in wanted:
+            # the c5 legs bring their own pipeline (token-gated weights): release this one's handle first -- its workspace is
+            # tens of GB, and ranks that share a card in a rehearsal would not fit two per rank (six ranks: out of memory)
+            batches.clear()
+            model.net.close()
+            torch.cuda.empty_cache()
             legs5 = bench_multi.c5_legs(rank, world, args.c5_reads_per_rank, threads=4, cpuset=my_cpus,
                                         keep_dir=os.environ.get("DC_BENCH_KEEP_DIR") or None)
             if rank == 0:
