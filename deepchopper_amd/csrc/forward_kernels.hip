@@ -606,7 +606,13 @@ __global__ __launch_bounds__(64 * DC_H_NW, DC_H_OCC) void gemm6_kernel(GemmArgs 
   constexpr int H_A_BYTES = SM::NP * H_BK * H_BN * 2;
   constexpr int BUF = H_A_BYTES + H_B_BYTES;
   constexpr int EPI_BYTES = H_NW * 32 * 32 * 4;
-  constexpr int S = DC_H_STAGES;  // LDS ring depth: tiles kt+1 .. kt+S-1 are in flight while tile kt is consumed
+  // LDS ring depth: tiles kt+1 .. kt+S-1 are in flight while tile kt is consumed.  bf16x6 (three A planes: 28 KiB per stage):
+  // three stages are 84 KiB = ONE workgroup per CU; two stages are 56 KiB = two workgroups per CU, i.e. four waves per SIMD
+  // instead of two to hide the tile latency with (round 6; DC_H_STAGES6 overrides, A/B)
+#ifndef DC_H_STAGES6
+#define DC_H_STAGES6 2
+#endif
+  constexpr int S = MODE == 0 ? DC_H_STAGES6 : DC_H_STAGES;
   constexpr int SMEM = (S * BUF > EPI_BYTES) ? S * BUF : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem6[SMEM];
 
